@@ -1,0 +1,154 @@
+"""Oracle (test infrastructure): LightGlue forward pass on PyTorch-CPU fp32.
+
+Restates gluefactory/models/matchers/lightglue.py (inference path, no early stop /
+pruning: depth_confidence = width_confidence = -1 in every target config).  Weights
+come as a state dict with the reference's key names (lightglue.py:349-408).
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+def normalize_keypoints(kpts: Tensor, size: Optional[Tensor]) -> Tensor:
+    """lightglue.py:28-40: centre on size/2 and divide by max(size)/2; size=[w,h] per image.
+    Without a size the extent of the keypoints themselves is used."""
+    if size is None:
+        size = 1 + kpts.max(-2).values - kpts.min(-2).values
+    size = torch.as_tensor(size).to(kpts)
+    centre = size / 2
+    half_extent = size.max(-1).values / 2
+    return (kpts - centre[..., None, :]) / half_extent[..., None, None]
+
+
+def positional_encoding(wr: Tensor, kpts: Tensor) -> Tensor:
+    """lightglue.py:53-66: angles = kpts @ Wr^T [B,N,32]; returns [2,B,1,N,64] with every
+    cos / sin value repeated twice along the last axis."""
+    ang = kpts @ wr.t()
+    enc = torch.stack([ang.cos(), ang.sin()], 0).unsqueeze(-3)
+    return enc.repeat_interleave(2, dim=-1)
+
+
+def rotary(enc: Tensor, t: Tensor) -> Tensor:
+    """lightglue.py:43-50: t*cos + rot(t)*sin where rot maps adjacent pairs (a,b) -> (-b,a)."""
+    pairs = t.unflatten(-1, (-1, 2))
+    rot = torch.stack([-pairs[..., 1], pairs[..., 0]], -1).flatten(-2)
+    return t * enc[0] + rot * enc[1]
+
+
+def _linear(sd, name, x):
+    return F.linear(x, sd[name + ".weight"], sd.get(name + ".bias"))
+
+
+def _ffn(sd, prefix, x):
+    """Linear(2d,2d) -> LayerNorm(2d, eps 1e-5) -> GELU(erf) -> Linear(2d,d)  (lightglue.py:143-148)."""
+    h = _linear(sd, prefix + ".0", x)
+    h = F.layer_norm(h, (h.shape[-1],), sd[prefix + ".1.weight"], sd[prefix + ".1.bias"], eps=1e-5)
+    return _linear(sd, prefix + ".3", F.gelu(h))
+
+
+def self_block(sd: Dict[str, Tensor], p: str, x: Tensor, enc: Tensor, heads: int) -> Tensor:
+    """lightglue.py:151-164.  The fused projection's output channel is head*(3*dh) + d*3 + {q,k,v}."""
+    b, n, d = x.shape
+    qkv = _linear(sd, p + ".Wqkv", x).view(b, n, heads, d // heads, 3).permute(0, 2, 1, 3, 4)
+    q, k, v = rotary(enc, qkv[..., 0]), rotary(enc, qkv[..., 1]), qkv[..., 2]
+    att = torch.softmax((q @ k.transpose(-1, -2)) * (q.shape[-1] ** -0.5), -1)
+    ctx = (att @ v).transpose(1, 2).reshape(b, n, d)
+    msg = _linear(sd, p + ".out_proj", ctx)
+    return x + _ffn(sd, p + ".ffn", torch.cat([x, msg], -1))
+
+
+def cross_block(sd: Dict[str, Tensor], p: str, x0: Tensor, x1: Tensor, heads: int):
+    """lightglue.py:193-222 (non-flash branch): one similarity matrix, soft-maxed along rows
+    for the 0->1 messages and along columns for the 1->0 messages."""
+    def split(t):
+        b, n, d = t.shape
+        return t.view(b, n, heads, d // heads).transpose(1, 2)
+
+    qk0, qk1 = split(_linear(sd, p + ".to_qk", x0)), split(_linear(sd, p + ".to_qk", x1))
+    v0, v1 = split(_linear(sd, p + ".to_v", x0)), split(_linear(sd, p + ".to_v", x1))
+    s = (qk0.shape[-1] ** -0.5) ** 0.5
+    sim = (qk0 * s) @ (qk1 * s).transpose(-1, -2)
+    m0 = torch.softmax(sim, -1) @ v1
+    m1 = torch.softmax(sim.transpose(-1, -2), -1) @ v0
+
+    def merge(t):
+        b, h, n, dh = t.shape
+        return t.transpose(1, 2).reshape(b, n, h * dh)
+
+    m0, m1 = _linear(sd, p + ".to_out", merge(m0)), _linear(sd, p + ".to_out", merge(m1))
+    x0 = x0 + _ffn(sd, p + ".ffn", torch.cat([x0, m0], -1))
+    x1 = x1 + _ffn(sd, p + ".ffn", torch.cat([x1, m1], -1))
+    return x0, x1
+
+
+def log_double_softmax(sim: Tensor, z0: Tensor, z1: Tensor) -> Tensor:
+    """lightglue.py:257-269.  sim [B,M,N], z0 [B,M,1], z1 [B,N,1] -> [B,M+1,N+1]."""
+    b, m, n = sim.shape
+    out = sim.new_zeros((b, m + 1, n + 1))
+    rows = F.log_softmax(sim, 2)
+    cols = F.log_softmax(sim, 1)
+    out[:, :m, :n] = rows + cols + (F.logsigmoid(z0) + F.logsigmoid(z1).transpose(1, 2))
+    out[:, :m, n] = F.logsigmoid(-z0.squeeze(-1))
+    out[:, m, :n] = F.logsigmoid(-z1.squeeze(-1))
+    return out
+
+
+def match_assignment(sd: Dict[str, Tensor], p: str, x0: Tensor, x1: Tensor) -> Tensor:
+    """lightglue.py:279-288: projected descriptors each divided by d^(1/4)."""
+    d = x0.shape[-1]
+    a = _linear(sd, p + ".final_proj", x0) / d ** 0.25
+    c = _linear(sd, p + ".final_proj", x1) / d ** 0.25
+    sim = a @ c.transpose(1, 2)
+    return log_double_softmax(sim, _linear(sd, p + ".matchability", x0), _linear(sd, p + ".matchability", x1))
+
+
+def filter_matches(scores: Tensor, th: float):
+    """lightglue.py:294-319: mutual arg-max over the inner [M,N] block, score = exp(max),
+    keep mutual pairs with score > th.  Returns (m0 int64 [B,M], m1 int64 [B,N], s0, s1)."""
+    b, m, n = scores.shape[0], scores.shape[1] - 1, scores.shape[2] - 1
+    if m == 0 or n == 0:
+        return (torch.full((b, m), -1, dtype=torch.long), torch.full((b, n), -1, dtype=torch.long),
+                scores.new_zeros((b, m)), scores.new_zeros((b, n)))
+    inner = scores[:, :m, :n]
+    best0, best1 = inner.max(2), inner.max(1)
+    i0, i1 = best0.indices, best1.indices
+    mutual0 = torch.arange(m)[None] == i1.gather(1, i0)
+    mutual1 = torch.arange(n)[None] == i0.gather(1, i1)
+    s0 = torch.where(mutual0, best0.values.exp(), best0.values.new_zeros(()))
+    s1 = torch.where(mutual1, s0.gather(1, i1), s0.new_zeros(()))
+    ok0 = mutual0 & (s0 > th)
+    ok1 = mutual1 & ok0.gather(1, i1)
+    return torch.where(ok0, i0, -1), torch.where(ok1, i1, -1), s0, s1
+
+
+def match(sd: Dict[str, Tensor], kpts0: Tensor, kpts1: Tensor, desc0: Tensor, desc1: Tensor,
+          size0: Optional[Tensor], size1: Optional[Tensor], n_layers: int = 9, heads: int = 4,
+          filter_threshold: float = 0.0, return_layers: bool = False) -> Dict[str, Tensor]:
+    """lightglue.py:422-553 with early stopping and pruning disabled."""
+    with torch.no_grad():
+        k0 = normalize_keypoints(kpts0, size0)
+        k1 = normalize_keypoints(kpts1, size1)
+        x0, x1 = desc0.contiguous(), desc1.contiguous()
+        if "input_proj.weight" in sd:
+            x0, x1 = _linear(sd, "input_proj", x0), _linear(sd, "input_proj", x1)
+        e0 = positional_encoding(sd["posenc.Wr.weight"], k0)
+        e1 = positional_encoding(sd["posenc.Wr.weight"], k1)
+        layers = []
+        for i in range(n_layers):
+            x0 = self_block(sd, f"transformers.{i}.self_attn", x0, e0, heads)
+            x1 = self_block(sd, f"transformers.{i}.self_attn", x1, e1, heads)
+            x0, x1 = cross_block(sd, f"transformers.{i}.cross_attn", x0, x1, heads)
+            if return_layers:
+                layers.append((x0.clone(), x1.clone()))
+        scores = match_assignment(sd, f"log_assignment.{n_layers - 1}", x0, x1)
+        m0, m1, s0, s1 = filter_matches(scores, filter_threshold)
+    out = {"matches0": m0, "matches1": m1, "matching_scores0": s0, "matching_scores1": s1,
+           "ref_descriptors0": x0[:, None], "ref_descriptors1": x1[:, None], "log_assignment": scores,
+           "prune0": torch.ones_like(s0) * n_layers, "prune1": torch.ones_like(s1) * n_layers}
+    if return_layers:
+        out["layers"] = layers
+    return out

@@ -1,0 +1,309 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own modules.
+
+Runs only in the build container, where /root/reference exists (it does not travel to
+the GPU box; the tests read the committed .npz files, never the reference).  The
+reference needs `omegaconf`, which is absent here: `tests/golden/_standins/omegaconf`
+is a ~100-line stand-in written for this script.  No network access is
+made: weights come from glue_factory_colon_amd.weights (name-seeded), the open
+SuperPoint takes them through its local-file branch (superpoint_open.py:120-121), the
+in-tree LightGlue through load_state_dict, and for the official SuperPoint class the
+URL fetch in its constructor is redirected to the same generated state dict.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Fixtures hold inputs and reference outputs only (data), in float32 / int64.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("GFC_REFERENCE", "/root/reference")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "_standins"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from glue_factory_colon_amd import synthetic, weights  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.manual_seed(0)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KB, keys={sorted(arrays)}")
+
+
+# ------------------------------------------------------------------ reference modules
+from gluefactory.models.extractors import superpoint_open as ref_spo  # noqa: E402
+from gluefactory.models.matchers import lightglue as ref_lg  # noqa: E402
+from gluefactory.models.two_view_pipeline import TwoViewPipeline  # noqa: E402
+import gluefactory_nonfree.superpoint as ref_sp  # noqa: E402
+
+_tmp = tempfile.mkdtemp()
+SPO_PATH = os.path.join(_tmp, "spo_seed0.pth")
+torch.save(weights.superpoint_open_state_dict(0), SPO_PATH)
+
+
+def make_spo(**conf):
+    return ref_spo.SuperPoint({"weights": SPO_PATH, **conf}).eval()
+
+
+def make_sp_official(**conf):
+    sd = weights.superpoint_state_dict(0)
+    orig = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: sd  # no network: constructor fetch redirected
+    try:
+        m = ref_sp.SuperPoint(conf).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = orig
+    return m
+
+
+def make_lg(input_dim=256, **conf):
+    m = ref_lg.LightGlue({"input_dim": input_dim, **conf}).eval()
+    missing = m.load_state_dict(weights.lightglue_state_dict(0, input_dim=input_dim), strict=False)
+    assert missing.missing_keys == ["confidence_thresholds"] and not missing.unexpected_keys, missing
+    return m
+
+
+# --------------------------------------------------------------------------- NMS cases
+def golden_nms():
+    g = torch.Generator().manual_seed(7)
+    out = {}
+    for r in (0, 1, 3, 4):
+        s = torch.rand((2, 45, 70), generator=g)
+        # plateaus and exact ties: quantise one image, add a constant patch and zeros
+        s[1] = (s[1] * 8).round() / 8
+        s[0, 10:14, 20:30] = 0.75
+        s[0, 30:, :5] = 0.0
+        out[f"in_r{r}"] = npy(s)
+        out[f"out_r{r}"] = npy(ref_spo.batched_nms(s, r))
+        out[f"out_official_r{r}"] = npy(ref_sp.simple_nms(s, r))
+    save("nms", **out)
+
+
+# ----------------------------------------------------------------------- SuperPoint-open
+def golden_superpoint_open():
+    img = synthetic.synthetic_images(2, 120, 160, seed=11)
+    out = {"image": npy(img)}
+    # stage tensors through the reference's own sub-modules
+    m = make_spo(max_num_keypoints=150, detection_threshold=0.0, nms_radius=3, dense_outputs=True)
+    feats = m.backbone(img)
+    logits = m.detector(feats)
+    out["logits"] = npy(logits)
+    heat = torch.softmax(logits, 1)[:, :-1]
+    b, _, h, w = heat.shape
+    heat = heat.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
+    out["heatmap"] = npy(heat)
+    out["nms_r3"] = npy(ref_spo.batched_nms(heat, 3))
+    for i in range(2):  # b == 1 calls (the eval configuration)
+        p = m({"image": img[i:i + 1]})
+        out[f"k150_kpts_{i}"] = npy(p["keypoints"][0])
+        out[f"k150_scores_{i}"] = npy(p["keypoint_scores"][0])
+        out[f"k150_desc_{i}"] = npy(p["descriptors"][0])
+        if i == 0:
+            out["dense_desc_0"] = npy(p["dense_descriptors"][0])
+    # fewer detections than k: all candidates, row-major, unsorted (superpoint_open.py:54-58)
+    m2 = make_spo(max_num_keypoints=4096, detection_threshold=0.0, nms_radius=4)
+    p = m2({"image": img[:1]})
+    out["k4096_r4_kpts_0"] = npy(p["keypoints"][0])
+    out["k4096_r4_scores_0"] = npy(p["keypoint_scores"][0])
+    out["k4096_r4_desc_0"] = npy(p["descriptors"][0])
+    # threshold > 0, no NMS radius 0 (scripts/eval_hpatches.sh uses nms_radius 0), RGB input
+    rgb = torch.cat([img[:1] * 0.9, img[:1], img[:1] * 0.8], 1).clamp(0, 1)
+    out["image_rgb"] = npy(rgb)
+    m3 = make_spo(max_num_keypoints=100, detection_threshold=0.02, nms_radius=0, remove_borders=6)
+    p = m3({"image": rgb})
+    out["rgb_r0_kpts"] = npy(p["keypoints"][0])
+    out["rgb_r0_scores"] = npy(p["keypoint_scores"][0])
+    out["rgb_r0_desc"] = npy(p["descriptors"][0])
+    # batched call with force_num_keypoints (every image has >= k detections: no random padding)
+    m4 = make_spo(max_num_keypoints=64, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    p = m4({"image": img})
+    out["b2_k64_kpts"] = npy(p["keypoints"])
+    out["b2_k64_scores"] = npy(p["keypoint_scores"])
+    out["b2_k64_desc"] = npy(p["descriptors"])
+    save("superpoint_open", **out)
+
+
+# ------------------------------------------------------------------- SuperPoint official
+def golden_superpoint_official():
+    img = synthetic.synthetic_images(1, 104, 136, seed=21)
+    out = {"image": npy(img)}
+    m = make_sp_official(max_num_keypoints=120, detection_threshold=0.0, nms_radius=3, sparse_outputs=False)
+    p = m({"image": img})
+    out["heatmap"] = npy(p["keypoint_scores"])
+    out["dense_desc"] = npy(p["descriptors"])
+    for legacy in (True, False):
+        m = make_sp_official(max_num_keypoints=120, detection_threshold=0.0, nms_radius=3, legacy_sampling=legacy)
+        p = m({"image": img})
+        tag = "legacy" if legacy else "fixed"
+        out[f"{tag}_kpts"] = npy(p["keypoints"][0])
+        out[f"{tag}_scores"] = npy(p["keypoint_scores"][0])
+        out[f"{tag}_desc"] = npy(p["descriptors"][0])
+    # image_size smaller than the tensor: right / bottom borders follow the true extent
+    size = torch.tensor([[120.0, 90.0]])
+    m = make_sp_official(max_num_keypoints=-1, detection_threshold=0.01, nms_radius=4)
+    p = m({"image": img, "image_size": size})
+    out["sized_image_size"] = npy(size)
+    out["sized_kpts"] = npy(p["keypoints"][0])
+    out["sized_scores"] = npy(p["keypoint_scores"][0])
+    out["sized_desc"] = npy(p["descriptors"][0])
+    save("superpoint_official", **out)
+
+
+# ---------------------------------------------------------------------------- LightGlue
+def _features(n_img, h, w, k, seed):
+    """Run reference SuperPoint-open on synthetic pairs to obtain realistic LightGlue inputs."""
+    v0, v1 = synthetic.synthetic_pairs(n_img, h, w, seed=seed, dx=16, dy=8)
+    m = make_spo(max_num_keypoints=k, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    return v0, v1, m({"image": v0}), m({"image": v1})
+
+
+def golden_lightglue():
+    h, w, k = 120, 160, 160
+    v0, v1, p0, p1 = _features(2, h, w, k, seed=31)
+    size = torch.tensor([[w, h]] * 2, dtype=torch.float32)
+    data = {"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"],
+            "descriptors0": p0["descriptors"], "descriptors1": p1["descriptors"],
+            "view0": {"image_size": size}, "view1": {"image_size": size}}
+    out = {k_: npy(v) for k_, v in data.items() if not k_.startswith("view")}
+    out["image_size"] = npy(size)
+    lg = make_lg(filter_threshold=0.1)
+    # per-layer descriptors through the reference's own layer modules
+    k0 = ref_lg.normalize_keypoints(data["keypoints0"], size).clone()
+    k1 = ref_lg.normalize_keypoints(data["keypoints1"], size).clone()
+    e0, e1 = lg.posenc(k0), lg.posenc(k1)
+    out["enc0"] = npy(e0)
+    d0, d1 = data["descriptors0"], data["descriptors1"]
+    s0 = lg.transformers[0].self_attn(d0, e0)
+    out["layer0_self0"] = npy(s0)
+    for i in range(9):
+        d0, d1 = lg.transformers[i](d0, d1, e0, e1)
+        if i in (0, 4):
+            out[f"layer{i}_desc0"] = npy(d0)
+            out[f"layer{i}_desc1"] = npy(d1)
+    pred = lg(data)
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment",
+                "ref_descriptors0", "ref_descriptors1", "prune0"):
+        out["b2_" + key] = npy(pred[key])
+    # threshold 0.0 (the module default)
+    pred = make_lg(filter_threshold=0.0)(data)
+    out["th0_matches0"] = npy(pred["matches0"])
+    out["th0_matches1"] = npy(pred["matches1"])
+    # ragged pair, b == 1: M != N
+    data1 = {"keypoints0": p0["keypoints"][:1, :100], "keypoints1": p1["keypoints"][:1],
+             "descriptors0": p0["descriptors"][:1, :100], "descriptors1": p1["descriptors"][:1],
+             "view0": {"image_size": size[:1]}, "view1": {"image_size": size[:1]}}
+    pred = lg(data1)
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment"):
+        out["ragged_" + key] = npy(pred[key])
+    # 128-d descriptors (DISK-style input, input_proj Linear 128->256, lightglue.py:352-355)
+    g = torch.Generator().manual_seed(5)
+    dd0 = torch.nn.functional.normalize(torch.randn((1, 96, 128), generator=g), dim=-1)
+    perm = torch.randperm(96, generator=g)
+    dd1 = torch.nn.functional.normalize(dd0[:, perm] + 0.05 * torch.randn((1, 96, 128), generator=g), dim=-1)
+    kk0 = torch.rand((1, 96, 2), generator=g) * torch.tensor([w, h])
+    kk1 = kk0[:, perm] + torch.tensor([3.0, -2.0])
+    lg128 = make_lg(input_dim=128, filter_threshold=0.1)
+    pred = lg128({"keypoints0": kk0, "keypoints1": kk1, "descriptors0": dd0, "descriptors1": dd1,
+                  "view0": {"image_size": size[:1]}, "view1": {"image_size": size[:1]}})
+    out.update(d128_keypoints0=npy(kk0), d128_keypoints1=npy(kk1), d128_descriptors0=npy(dd0),
+               d128_descriptors1=npy(dd1))
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment"):
+        out["d128_" + key] = npy(pred[key])
+    save("lightglue", **out)
+
+
+def golden_assignment():
+    """sigmoid_log_double_softmax + filter_matches on crafted inputs with exact ties, a
+    threshold edge and the empty-set early return (lightglue.py:257-269,294-319)."""
+    g = torch.Generator().manual_seed(3)
+    sim = torch.randn((2, 37, 53), generator=g) * 3
+    sim[0, 5] = sim[0, 4]  # duplicate rows -> tied column maxima
+    sim[1, :, 7] = sim[1, :, 6]  # duplicate columns -> tied row maxima
+    sim = (sim * 4).round() / 4
+    z0 = torch.randn((2, 37, 1), generator=g)
+    z1 = torch.randn((2, 53, 1), generator=g)
+    la = ref_lg.sigmoid_log_double_softmax(sim, z0, z1)
+    out = {"sim": npy(sim), "z0": npy(z0), "z1": npy(z1), "log_assignment": npy(la)}
+    for th in (0.0, 0.1, 0.5):
+        m0, m1, s0, s1 = ref_lg.filter_matches(la, th)
+        tag = str(th).replace(".", "p")
+        out.update({f"m0_{tag}": npy(m0), f"m1_{tag}": npy(m1), f"s0_{tag}": npy(s0), f"s1_{tag}": npy(s1)})
+    # a permutation-like assignment with large margins: everything matches
+    perm = torch.randperm(40, generator=g)
+    sim2 = torch.full((1, 40, 40), -5.0)
+    sim2[0, torch.arange(40), perm] = 12.0
+    la2 = ref_lg.sigmoid_log_double_softmax(sim2, torch.full((1, 40, 1), 4.0), torch.full((1, 40, 1), 4.0))
+    m0, m1, s0, s1 = ref_lg.filter_matches(la2, 0.1)
+    out.update(perm_log_assignment=npy(la2), perm_m0=npy(m0), perm_m1=npy(m1), perm_s0=npy(s0), perm_s1=npy(s1))
+    m0, m1, s0, s1 = ref_lg.filter_matches(torch.zeros((2, 1, 6)), 0.1)
+    out.update(empty_m0=npy(m0), empty_m1=npy(m1), empty_s0=npy(s0), empty_s1=npy(s1))
+    save("assignment", **out)
+
+
+# ---------------------------------------------------------------------------- pipeline
+def golden_pipeline():
+    """TwoViewPipeline (two_view_pipeline.py:278-405) on a synthetic pair and on the
+    boat pair of tests/test_integration.py (down-sampled grey crop stored as uint8)."""
+    out = {}
+    conf = {"extractor": {"name": "extractors.superpoint_open", "weights": SPO_PATH, "max_num_keypoints": 256,
+                          "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "flash": False}}
+    pipe = TwoViewPipeline(conf).eval()
+    pipe.matcher.load_state_dict(weights.lightglue_state_dict(0), strict=False)
+    v0, v1 = synthetic.synthetic_pairs(1, 160, 208, seed=41, dx=16, dy=8)
+    size = torch.tensor([[208.0, 160.0]])
+    pred = pipe({"view0": {"image": v0, "image_size": size}, "view1": {"image": v1, "image_size": size}})
+    out["syn_image0"] = (npy(v0) * 255).round().astype(np.uint8)  # inputs stored as uint8: exact in fp32 /255
+    out["syn_image1"] = (npy(v1) * 255).round().astype(np.uint8)
+    v0q = torch.from_numpy(out["syn_image0"].astype(np.float32) / 255)
+    v1q = torch.from_numpy(out["syn_image1"].astype(np.float32) / 255)
+    pred = pipe({"view0": {"image": v0q, "image_size": size}, "view1": {"image": v1q, "image_size": size}})
+    keys = ("keypoints0", "keypoints1", "keypoint_scores0", "keypoint_scores1", "descriptors0", "descriptors1",
+            "matches0", "matches1", "matching_scores0", "matching_scores1")
+    for key in keys:
+        out["syn_" + key] = npy(pred[key])
+    out["syn_pred_keys"] = np.array(sorted(pred.keys()))
+    # boat pair (C1): PIL decode, grey, 2x box down-sample, crop to a multiple of 8
+    from PIL import Image
+
+    def boat(name):
+        im = Image.open(os.path.join(REF, "assets", name)).convert("L")
+        im = im.resize((im.width // 2, im.height // 2), Image.BOX)
+        a = np.asarray(im, dtype=np.uint8)
+        return a[: a.shape[0] // 8 * 8, : a.shape[1] // 8 * 8]
+
+    b0, b1 = boat("boat1.png"), boat("boat2.png")
+    out["boat_image0"], out["boat_image1"] = b0, b1
+    t0 = torch.from_numpy(b0.astype(np.float32) / 255)[None, None]
+    t1 = torch.from_numpy(b1.astype(np.float32) / 255)[None, None]
+    s0 = torch.tensor([[float(b0.shape[1]), float(b0.shape[0])]])
+    s1 = torch.tensor([[float(b1.shape[1]), float(b1.shape[0])]])
+    pred = pipe({"view0": {"image": t0, "image_size": s0}, "view1": {"image": t1, "image_size": s1}})
+    for key in keys:
+        if key.startswith("descriptors"):
+            continue
+        out["boat_" + key] = npy(pred[key])
+    save("pipeline", **out)
+
+
+if __name__ == "__main__":
+    golden_nms()
+    golden_assignment()
+    golden_superpoint_open()
+    golden_superpoint_official()
+    golden_lightglue()
+    golden_pipeline()

@@ -1,0 +1,130 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference's own
+modules (tests/golden/make_golden.py).  Indices / counts bit-exact, floats <= 1e-5
+(the north-star tolerance for the HIP path is 1e-4; the oracle itself sits much closer)."""
+import pytest
+import torch
+
+from glue_factory_colon_amd import weights
+from oracle import lightglue as olg
+from oracle import superpoint as osp
+
+TOL = 1e-5
+
+
+def close(a, b, tol=TOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a.double() - b.double()).abs().max().item() if a.numel() else 0.0
+    assert err <= tol, err
+
+
+@pytest.mark.parametrize("r", [0, 1, 3, 4])
+def test_nms_bit_exact(golden, r):
+    g = golden("nms")
+    out = osp.nms(g[f"in_r{r}"], r)
+    assert torch.equal(out, g[f"out_r{r}"])
+    assert torch.equal(out, g[f"out_official_r{r}"])
+
+
+def test_assignment_and_filter(golden):
+    g = golden("assignment")
+    la = olg.log_double_softmax(g["sim"], g["z0"], g["z1"])
+    close(la, g["log_assignment"], 1e-5)
+    for th, tag in ((0.0, "0p0"), (0.1, "0p1"), (0.5, "0p5")):
+        m0, m1, s0, s1 = olg.filter_matches(g["log_assignment"], th)
+        assert torch.equal(m0, g[f"m0_{tag}"]) and torch.equal(m1, g[f"m1_{tag}"])
+        assert torch.equal(s0, g[f"s0_{tag}"]) and torch.equal(s1, g[f"s1_{tag}"])
+    m0, m1, s0, s1 = olg.filter_matches(g["perm_log_assignment"], 0.1)
+    assert torch.equal(m0, g["perm_m0"]) and torch.equal(m1, g["perm_m1"])
+    assert (m0 >= 0).all()
+    m0, m1, s0, s1 = olg.filter_matches(torch.zeros((2, 1, 6)), 0.1)
+    assert torch.equal(m0, g["empty_m0"]) and torch.equal(m1, g["empty_m1"])
+    assert m0.shape == (2, 0) and m1.shape == (2, 5) and m1.dtype == torch.int64
+
+
+def test_superpoint_open_stages(golden):
+    g = golden("superpoint_open")
+    sd = weights.superpoint_open_state_dict(0)
+    heat, dense = osp.dense_open(sd, g["image"])
+    close(heat, g["heatmap"], 1e-6)
+    close(dense[0], g["dense_desc_0"], 1e-5)
+    close(osp.logits_to_heatmap(g["logits"]), g["heatmap"], 1e-7)
+    assert torch.equal(osp.nms(g["heatmap"], 3), g["nms_r3"])
+
+
+def test_superpoint_open_outputs(golden):
+    g = golden("superpoint_open")
+    sd = weights.superpoint_open_state_dict(0)
+    out = osp.extract(sd, g["image"], "open", nms_radius=3, max_num_keypoints=150, detection_threshold=0.0)
+    for i in range(2):
+        assert torch.equal(out["keypoints"][i], g[f"k150_kpts_{i}"])
+        close(out["keypoint_scores"][i], g[f"k150_scores_{i}"], 1e-6)
+        close(out["descriptors"][i], g[f"k150_desc_{i}"])
+    out = osp.extract(sd, g["image"][:1], "open", nms_radius=4, max_num_keypoints=4096, detection_threshold=0.0)
+    assert out["keypoints"][0].shape[0] < 4096  # fewer than k: all candidates, row-major order
+    assert torch.equal(out["keypoints"][0], g["k4096_r4_kpts_0"])
+    close(out["descriptors"][0], g["k4096_r4_desc_0"])
+    out = osp.extract(sd, g["image_rgb"], "open", nms_radius=0, max_num_keypoints=100, detection_threshold=0.02,
+                      remove_borders=6)
+    assert torch.equal(out["keypoints"][0], g["rgb_r0_kpts"])
+    close(out["keypoint_scores"][0], g["rgb_r0_scores"], 1e-6)
+    close(out["descriptors"][0], g["rgb_r0_desc"])
+    out = osp.extract(sd, g["image"], "open", nms_radius=3, max_num_keypoints=64, detection_threshold=0.0)
+    assert torch.equal(torch.stack(out["keypoints"]), g["b2_k64_kpts"])
+    close(torch.stack(out["descriptors"]), g["b2_k64_desc"])
+
+
+def test_superpoint_official(golden):
+    g = golden("superpoint_official")
+    sd = weights.superpoint_state_dict(0)
+    heat, dense = osp.dense_official(sd, g["image"])
+    close(heat, g["heatmap"], 1e-6)
+    close(dense, g["dense_desc"], 1e-5)
+    for legacy, tag in ((True, "legacy"), (False, "fixed")):
+        out = osp.extract(sd, g["image"], "official", nms_radius=3, max_num_keypoints=120,
+                          detection_threshold=0.0, legacy_sampling=legacy)
+        assert torch.equal(out["keypoints"][0], g[f"{tag}_kpts"])
+        close(out["keypoint_scores"][0], g[f"{tag}_scores"], 1e-6)
+        close(out["descriptors"][0], g[f"{tag}_desc"])
+    out = osp.extract(sd, g["image"], "official", nms_radius=4, max_num_keypoints=-1, detection_threshold=0.01,
+                      image_size=g["sized_image_size"])
+    assert torch.equal(out["keypoints"][0], g["sized_kpts"])
+    close(out["descriptors"][0], g["sized_desc"])
+    assert out["keypoints"][0][:, 0].max() < 120 - 4 + 0.5 and out["keypoints"][0][:, 1].max() < 90 - 4 + 0.5
+
+
+def test_lightglue_layers_and_matches(golden):
+    g = golden("lightglue")
+    sd = weights.lightglue_state_dict(0)
+    k0 = olg.normalize_keypoints(g["keypoints0"], g["image_size"])
+    e0 = olg.positional_encoding(sd["posenc.Wr.weight"], k0)
+    close(e0, g["enc0"], 1e-6)
+    close(olg.self_block(sd, "transformers.0.self_attn", g["descriptors0"], e0, 4), g["layer0_self0"])
+    out = olg.match(sd, g["keypoints0"], g["keypoints1"], g["descriptors0"], g["descriptors1"], g["image_size"],
+                    g["image_size"], filter_threshold=0.1, return_layers=True)
+    close(out["layers"][0][0], g["layer0_desc0"], 2e-5)
+    close(out["layers"][4][1], g["layer4_desc1"], 5e-5)
+    close(out["ref_descriptors0"], g["b2_ref_descriptors0"], 1e-4)
+    close(out["log_assignment"], g["b2_log_assignment"], 1e-3)
+    assert torch.equal(out["matches0"], g["b2_matches0"]) and torch.equal(out["matches1"], g["b2_matches1"])
+    assert (out["matches0"] >= 0).sum() > 30  # non-trivial assignment
+    close(out["matching_scores0"], g["b2_matching_scores0"], 1e-4)
+    close(out["prune0"], g["b2_prune0"], 0)
+    out = olg.match(sd, g["keypoints0"], g["keypoints1"], g["descriptors0"], g["descriptors1"], g["image_size"],
+                    g["image_size"], filter_threshold=0.0)
+    assert torch.equal(out["matches0"], g["th0_matches0"]) and torch.equal(out["matches1"], g["th0_matches1"])
+
+
+def test_lightglue_ragged_and_128d(golden):
+    g = golden("lightglue")
+    sd = weights.lightglue_state_dict(0)
+    size = g["image_size"][:1]
+    out = olg.match(sd, g["keypoints0"][:1, :100], g["keypoints1"][:1], g["descriptors0"][:1, :100],
+                    g["descriptors1"][:1], size, size, filter_threshold=0.1)
+    assert out["log_assignment"].shape == (1, 101, 161)
+    assert torch.equal(out["matches0"], g["ragged_matches0"]) and torch.equal(out["matches1"], g["ragged_matches1"])
+    close(out["matching_scores1"], g["ragged_matching_scores1"], 1e-4)
+    sd128 = weights.lightglue_state_dict(0, input_dim=128)
+    out = olg.match(sd128, g["d128_keypoints0"], g["d128_keypoints1"], g["d128_descriptors0"],
+                    g["d128_descriptors1"], size, size, filter_threshold=0.1)
+    assert torch.equal(out["matches0"], g["d128_matches0"]) and torch.equal(out["matches1"], g["d128_matches1"])
+    close(out["log_assignment"], g["d128_log_assignment"], 1e-3)
