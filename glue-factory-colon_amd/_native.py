@@ -1,0 +1,130 @@
+"""ctypes binding of libgfc_amd.so (the C ABI declared in include/gfc_amd.h).
+
+The library is the product: if it is missing or a call fails, this module raises --
+there is no PyTorch / CPU fallback for any arithmetic on the path.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_longlong, c_size_t, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libgfc_amd.so")
+GFC_LG_MAX_LAYERS = 16
+
+STATUS = {0: "GFC_OK", 1: "GFC_ERR_INVALID", 2: "GFC_ERR_WORKSPACE", 3: "GFC_ERR_UNSUPPORTED", 4: "GFC_ERR_LAUNCH"}
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class SpParams(Structure):
+    _fields_ = [("w", c_void_p * 8), ("bias", c_void_p * 8), ("scale", c_void_p * 8), ("shift", c_void_p * 8),
+                ("wh", c_void_p), ("bias_h", c_void_p), ("scale_h", c_void_p), ("shift_h", c_void_p),
+                ("wp", c_void_p), ("bias_p", c_void_p), ("scale_p", c_void_p), ("shift_p", c_void_p),
+                ("wd", c_void_p), ("bias_d", c_void_p), ("scale_d", c_void_p), ("shift_d", c_void_p),
+                ("desc_dim", c_int)]
+
+
+_LG_ARRAYS = ["wqkv", "bqkv", "s_out_w", "s_out_b", "s_ffn0_w", "s_ffn0_b", "s_ln_g", "s_ln_b", "s_ffn3_w",
+              "s_ffn3_b", "c_qkv_w", "c_qkv_b", "c_out_w", "c_out_b", "c_ffn0_w", "c_ffn0_b", "c_ln_g", "c_ln_b",
+              "c_ffn3_w", "c_ffn3_b"]
+
+
+class LgParams(Structure):
+    _fields_ = ([("n_layers", c_int), ("input_dim", c_int), ("input_proj_w", c_void_p), ("input_proj_b", c_void_p),
+                 ("posenc_wr", c_void_p)]
+                + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in _LG_ARRAYS]
+                + [("final_proj_w", c_void_p), ("final_proj_b", c_void_p), ("matchability_w", c_void_p),
+                   ("matchability_b", c_void_p)])
+
+
+_lib = None
+
+# name -> (restype, argtypes); every symbol declared in include/gfc_amd.h
+SIGNATURES = {
+    "gfc_version": (c_char_p, []),
+    "gfc_pack_conv3x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gfc_conv3x3": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "gfc_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                           c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                           c_void_p]),
+    "gfc_batched_nt": (c_int, [c_void_p, c_int, c_longlong, c_void_p, c_int, c_longlong, c_void_p, c_int, c_longlong,
+                               c_int, c_int, c_int, c_int, c_void_p]),
+    "gfc_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                              c_int, c_int, c_float, c_void_p]),
+    "gfc_layernorm_gelu": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gfc_sp_workspace_bytes": (c_size_t, [c_int] * 4),
+    "gfc_sp_dense": (c_int, [POINTER(SpParams), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                             c_size_t, c_void_p]),
+    "gfc_sp_nms": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gfc_sp_select_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_sp_select": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "gfc_sp_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                              c_void_p, c_void_p]),
+    "gfc_l2norm_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p]),
+    "gfc_lg_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_lg_posenc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
+    "gfc_lg_log_assignment": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                      c_void_p]),
+    "gfc_lg_filter_matches": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_size_t, c_void_p]),
+    "gfc_lg_forward": (c_int, [POINTER(LgParams)] + [c_void_p] * 6 + [c_int] * 3 + [c_float] + [c_void_p] * 8
+                       + [c_size_t, c_void_p]),
+}
+
+
+def lib():
+    """Load libgfc_amd.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                f"{LIB_PATH} not found: build it with `python glue-factory-colon_amd/csrc/build.py` "
+                "(or __graft_entry__.build()).  There is no CPU fallback.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str):
+    if status != 0:
+        raise NativeError(f"{what} failed: {STATUS.get(status, status)}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous fp32/int32/int64."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "native calls need contiguous tensors"
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def require_cuda(t: torch.Tensor, name: str):
+    if t.device.type != "cuda":
+        raise NativeError(f"{name} is on {t.device}: the MI355X path needs tensors on a 'cuda' (ROCm) device; "
+                          "there is no CPU implementation in this package")
+
+
+class Workspace:
+    """Grow-only device scratch buffer (torch-allocated, passed to the library as void*)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes: int, device):
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
+            self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        return self.buf

@@ -1,0 +1,209 @@
+"""Host side shared by the two SuperPoint boundary modules: weight packing for the C ABI and the
+launch sequence dense -> NMS -> select -> (pad) -> sample.  Tensor plumbing only; all arithmetic
+happens in libgfc_amd.so.
+"""
+import ctypes
+import time
+
+import torch
+
+from . import _native as nat
+
+SAMPLE_OPEN, SAMPLE_LEGACY, SAMPLE_FIXED = 0, 1, 2
+
+
+def fold_bn(weight, bias, mean, var, eps=1e-3):
+    """Eval-mode BatchNorm as y = x*alpha + beta, with the same fp32 operation order as
+    torch's CPU kernel (invstd = 1/sqrt(var+eps); alpha = invstd*weight; beta = bias - mean*alpha)."""
+    invstd = 1.0 / torch.sqrt(var.float() + eps)
+    alpha = invstd * weight.float()
+    beta = bias.float() - mean.float() * alpha
+    return alpha, beta
+
+
+class PackedSuperPoint:
+    """Device-resident weights in the layouts of include/gfc_amd.h (gfc_sp_params)."""
+
+    def __init__(self, layers, head_p, head_d, pb, db, device):
+        """layers: 8 tuples (w_oihw, bias, scale|None, shift|None) for conv1a..conv4b;
+        head_p / head_d: 3x3 128->256 of detector / descriptor (same tuple form);
+        pb / db: 1x1 heads (w [C,256,1,1], bias, scale|None, shift|None)."""
+        lib = nat.lib()
+        st = nat.stream_ptr(device)
+        self.keep = []  # tensors referenced by raw pointers in the struct
+        self.params = nat.SpParams()
+
+        def dev(t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            self.keep.append(t)
+            return t
+
+        def pack3x3(w):
+            w = dev(w)
+            cout, cin = w.shape[0], w.shape[1]
+            out = torch.empty((9, cout, cin), device=device, dtype=torch.float32)
+            nat.check(lib.gfc_pack_conv3x3(nat.ptr(w), nat.ptr(out), cout, cin, st), "gfc_pack_conv3x3")
+            self.keep.append(out)
+            return out
+
+        def opt(t):
+            return None if t is None else dev(t)
+
+        for i, (w, b, sc, sh) in enumerate(layers):
+            self.params.w[i] = pack3x3(w).data_ptr()
+            self.params.bias[i] = dev(b).data_ptr()
+            sc, sh = opt(sc), opt(sh)
+            self.params.scale[i] = sc.data_ptr() if sc is not None else None
+            self.params.shift[i] = sh.data_ptr() if sh is not None else None
+        # merged 3x3 heads
+        wh = pack3x3(torch.cat([head_p[0], head_d[0]], 0))
+        bh = dev(torch.cat([head_p[1], head_d[1]], 0))
+        self.params.wh, self.params.bias_h = wh.data_ptr(), bh.data_ptr()
+        if head_p[2] is not None:
+            sch = dev(torch.cat([head_p[2], head_d[2]], 0))
+            shh = dev(torch.cat([head_p[3], head_d[3]], 0))
+            self.params.scale_h, self.params.shift_h = sch.data_ptr(), shh.data_ptr()
+        else:
+            self.params.scale_h = self.params.shift_h = None
+        for tag, (w, b, sc, sh) in (("p", pb), ("d", db)):
+            w = dev(w.reshape(w.shape[0], -1))
+            setattr(self.params, "w" + tag, w.data_ptr())
+            setattr(self.params, "bias_" + tag, dev(b).data_ptr())
+            sc, sh = opt(sc), opt(sh)
+            setattr(self.params, "scale_" + tag, sc.data_ptr() if sc is not None else None)
+            setattr(self.params, "shift_" + tag, sh.data_ptr() if sh is not None else None)
+        self.params.desc_dim = int(db[0].shape[0])
+        self.desc_dim = self.params.desc_dim
+        self.device = device
+
+
+def pad_random_c(kpts, scores, counts, k, low, high):
+    """`pad_and_stack(..., mode="random_c")` + zeros for the scores, on the device and without a
+    host synchronisation (gluefactory/models/utils/misc.py:19-62,103-113): slots >= count are
+    filled with per-column uniform samples in [min, max] of the image's own key points (bounds
+    [low, high] when the image has none).  The random stream is torch's device generator, so the
+    padded values themselves differ from the reference's CPU generator (they are random there too)."""
+    b, cap, _ = kpts.shape
+    idx = torch.arange(cap, device=kpts.device)[None, :, None]
+    valid = idx < counts[:, None, None]
+    big = torch.finfo(kpts.dtype).max
+    mn = torch.where(valid, kpts, kpts.new_full((), big)).amin(1, keepdim=True)
+    mx = torch.where(valid, kpts, kpts.new_full((), -big)).amax(1, keepdim=True)
+    empty = (counts == 0)[:, None, None]
+    mn = torch.where(empty, kpts.new_full((), float(low)), mn)
+    mx = torch.where(empty, kpts.new_full((), float(high)), mx)
+    fill = torch.rand((b, cap, 2), device=kpts.device, dtype=kpts.dtype) * (mx - mn) + mn
+    kpts = torch.where(valid, kpts, fill)
+    scores = torch.where(valid[..., 0], scores, scores.new_zeros(()))
+    return kpts[:, :k].contiguous(), scores[:, :k].contiguous()
+
+
+class SuperPointRunner:
+    """Launch sequence for one extractor call."""
+
+    def __init__(self):
+        self.ws = nat.Workspace()
+        self.ws_sel = nat.Workspace()
+
+    def dense(self, packed, image):
+        lib = nat.lib()
+        b, c, h, w = image.shape
+        dev = image.device
+        h8, w8 = h // 8, w // 8
+        heat = torch.empty((b, h8 * 8, w8 * 8), device=dev, dtype=torch.float32)
+        desc = torch.empty((b, h8, w8, packed.desc_dim), device=dev, dtype=torch.float32)
+        need = lib.gfc_sp_workspace_bytes(b, c, h, w)
+        ws = self.ws.get(need, dev)
+        nat.check(lib.gfc_sp_dense(ctypes.byref(packed.params), nat.ptr(image), b, c, h, w, nat.ptr(heat),
+                                   nat.ptr(desc), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "gfc_sp_dense")
+        return heat, desc
+
+    def nms(self, heat, radius, border, valid_wh=None):
+        lib = nat.lib()
+        b, h, w = heat.shape
+        out = torch.empty_like(heat)
+        nat.check(lib.gfc_sp_nms(nat.ptr(heat), b, h, w, int(radius), int(border), nat.ptr(valid_wh), nat.ptr(out),
+                                 nat.stream_ptr(heat.device)), "gfc_sp_nms")
+        return out
+
+    def select(self, scores, threshold, k):
+        """k: int >= 1, or None for unlimited.  Returns kpts [B,cap,2], kscores [B,cap], counts [B]."""
+        lib = nat.lib()
+        b, h, w = scores.shape
+        dev = scores.device
+        cap = int(k) if k is not None else h * w
+        kpts = torch.empty((b, cap, 2), device=dev, dtype=torch.float32)
+        ksc = torch.empty((b, cap), device=dev, dtype=torch.float32)
+        counts = torch.empty((b,), device=dev, dtype=torch.int32)
+        need = lib.gfc_sp_select_workspace_bytes(b, h, w)
+        ws = self.ws_sel.get(need, dev)
+        nat.check(lib.gfc_sp_select(nat.ptr(scores), b, h, w, float(threshold), int(k) if k is not None else -1, cap,
+                                    nat.ptr(kpts), nat.ptr(ksc), nat.ptr(counts), nat.ptr(ws), ws.numel(),
+                                    nat.stream_ptr(dev)), "gfc_sp_select")
+        return kpts, ksc, counts
+
+    def sample(self, desc_raw, kpts, counts, mode):
+        lib = nat.lib()
+        b, h8, w8, d = desc_raw.shape
+        cap = kpts.shape[1]
+        out = torch.empty((b, cap, d), device=kpts.device, dtype=torch.float32)
+        kout = torch.empty_like(kpts)
+        nat.check(lib.gfc_sp_sample(nat.ptr(desc_raw), b, h8, w8, d, nat.ptr(kpts), nat.ptr(counts), cap, int(mode),
+                                    nat.ptr(out), nat.ptr(kout), nat.stream_ptr(kpts.device)), "gfc_sp_sample")
+        return out, kout
+
+    def l2norm_rows(self, x):
+        lib = nat.lib()
+        rows = x.numel() // x.shape[-1]
+        nat.check(lib.gfc_l2norm_rows(nat.ptr(x), rows, x.shape[-1], nat.stream_ptr(x.device)), "gfc_l2norm_rows")
+        return x
+
+
+def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection_threshold, max_num_keypoints,
+                  force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs):
+    """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379)."""
+    image = data["image"]
+    nat.require_cuda(image, "data['image']")
+    if image.dtype != torch.float32:
+        image = image.float()
+    image = image.contiguous()
+    b = image.shape[0]
+    core_start = time.perf_counter()
+    heat, desc_raw = runner.dense(packed, image)
+    valid_wh = None
+    if use_image_size_for_borders and "image_size" in data and remove_borders:
+        valid_wh = data["image_size"].to(device=image.device).to(torch.int32).contiguous()
+    suppressed = runner.nms(heat, nms_radius, remove_borders or 0, valid_wh)
+    core_time_ms = (time.perf_counter() - core_start) * 1e3  # like the reference: no device sync
+
+    k = max_num_keypoints
+    kpts, ksc, counts = runner.select(suppressed, detection_threshold, k)
+    if force_num_keypoints:
+        if k is None:
+            raise ValueError("force_num_keypoints needs max_num_keypoints")
+        bound = data["image_size"].min().item() if "image_size" in data else min(image.shape[-2:])
+        kpts, ksc = pad_random_c(kpts, ksc, counts, k, 0, bound)
+        counts_arg = None
+    else:
+        n = counts.tolist()  # host sync, as torch.where in the reference
+        if len(set(n)) != 1:
+            # the reference cannot stack ragged key-point lists either (torch.stack raises)
+            raise RuntimeError(f"images of one batch yield different numbers of keypoints {n}: "
+                               "use force_num_keypoints=True or batch size 1")
+        kpts, ksc = kpts[:, : n[0]].contiguous(), ksc[:, : n[0]].contiguous()
+        counts_arg = None
+    if kpts.shape[1] > 0:
+        desc, kout = runner.sample(desc_raw, kpts, counts_arg, sample_mode)
+    else:
+        desc = kpts.new_zeros((b, 0, packed.desc_dim))
+        kout = kpts
+    pred = {
+        "keypoints": kout,
+        "keypoint_scores": ksc,
+        "descriptors": desc,
+        "extractor_core_time_ms": image.new_full((b,), core_time_ms / b),
+    }
+    if dense_outputs:
+        dense = runner.l2norm_rows(desc_raw.clone())
+        pred["dense_descriptors"] = dense.permute(0, 3, 1, 2)  # [B,C,h,w] view of the NHWC map
+    return pred

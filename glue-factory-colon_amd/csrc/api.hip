@@ -1,0 +1,247 @@
+// Host-side orchestration behind the C ABI: which kernels run, in which order, on which slices of
+// the caller's workspace.  No allocation, no synchronisation: everything is enqueued on the
+// caller's stream (graph-capturable).
+#include "common.h"
+
+// from the other translation units
+int gfc_rgb_to_gray(const float* img, float* out, int B, int H, int W, hipStream_t stream);
+int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* heat, hipStream_t st);
+int gfc_rowdot256(const float* x, int ld, int rows, const float* w, const float* bias, float* z, hipStream_t st);
+int gfc_assign_inplace(float* scores, const float* z0, const float* z1, int B, int M, int N, float* stats,
+                       hipStream_t st);
+
+extern "C" const char* gfc_version(void) { return "gfc_amd 0.1.0 (gfx950, fp32 MFMA)"; }
+
+#define GFC_TRY(expr)            \
+  do {                           \
+    int _s = (expr);             \
+    if (_s != GFC_OK) return _s; \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// SuperPoint dense forward
+// ---------------------------------------------------------------------------------------------
+struct SpPlan {
+  int H[5], W[5];  // resolution of stage 1..4 (index 1..4)
+  size_t gray, bufA, bufB;
+};
+
+static SpPlan sp_plan(int B, int C, int H, int W) {
+  SpPlan p;
+  p.H[1] = H; p.W[1] = W;
+  for (int i = 2; i <= 4; ++i) { p.H[i] = p.H[i - 1] / 2; p.W[i] = p.W[i - 1] / 2; }
+  p.gray = (C == 3) ? gfc_align((size_t)B * H * W * sizeof(float)) : 0;
+  size_t a = (size_t)B * H * W * 64;
+  size_t a4 = (size_t)B * p.H[4] * p.W[4] * 512;
+  if (a4 > a) a = a4;
+  size_t bsz = (size_t)B * p.H[2] * p.W[2] * 64;
+  size_t b3 = (size_t)B * p.H[3] * p.W[3] * 64, b4 = (size_t)B * p.H[4] * p.W[4] * 128;
+  if (b3 > bsz) bsz = b3;
+  if (b4 > bsz) bsz = b4;
+  p.bufA = gfc_align(a * sizeof(float));
+  p.bufB = gfc_align(bsz * sizeof(float));
+  return p;
+}
+
+extern "C" size_t gfc_sp_workspace_bytes(int B, int C, int H, int W) {
+  if (B <= 0 || H < 8 || W < 8) return 0;
+  SpPlan p = sp_plan(B, C, H, W);
+  return p.gray + p.bufA + p.bufB;
+}
+
+extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, int C, int H, int W, float* heatmap,
+                            float* desc_raw, void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !image || !heatmap || !desc_raw || !ws || B <= 0 || (C != 1 && C != 3) || H < 8 || W < 8)
+    return GFC_ERR_INVALID;
+  if (p->desc_dim <= 0) return GFC_ERR_INVALID;
+  if (ws_bytes < gfc_sp_workspace_bytes(B, C, H, W)) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  SpPlan pl = sp_plan(B, C, H, W);
+  char* base = (char*)ws;
+  float* gray = (float*)base;
+  float* A = (float*)(base + pl.gray);
+  float* Bf = (float*)(base + pl.gray + pl.bufA);
+  const float* x = image;
+  if (C == 3) {
+    GFC_TRY(gfc_rgb_to_gray(image, gray, B, H, W, st));
+    x = gray;
+  }
+  const int* Hs = pl.H;
+  const int* Ws = pl.W;
+  // conv1a, conv1b+pool
+  GFC_TRY(gfc_conv3x3(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], A, B, Hs[1], Ws[1], 1, 64, 1, 0, st));
+  GFC_TRY(gfc_conv3x3(A, p->w[1], p->bias[1], p->scale[1], p->shift[1], Bf, B, Hs[1], Ws[1], 64, 64, 1, 1, st));
+  // conv2a, conv2b+pool
+  GFC_TRY(gfc_conv3x3(Bf, p->w[2], p->bias[2], p->scale[2], p->shift[2], A, B, Hs[2], Ws[2], 64, 64, 1, 0, st));
+  GFC_TRY(gfc_conv3x3(A, p->w[3], p->bias[3], p->scale[3], p->shift[3], Bf, B, Hs[2], Ws[2], 64, 64, 1, 1, st));
+  // conv3a, conv3b+pool
+  GFC_TRY(gfc_conv3x3(Bf, p->w[4], p->bias[4], p->scale[4], p->shift[4], A, B, Hs[3], Ws[3], 64, 128, 1, 0, st));
+  GFC_TRY(gfc_conv3x3(A, p->w[5], p->bias[5], p->scale[5], p->shift[5], Bf, B, Hs[3], Ws[3], 128, 128, 1, 1, st));
+  // conv4a, conv4b
+  GFC_TRY(gfc_conv3x3(Bf, p->w[6], p->bias[6], p->scale[6], p->shift[6], A, B, Hs[4], Ws[4], 128, 128, 1, 0, st));
+  GFC_TRY(gfc_conv3x3(A, p->w[7], p->bias[7], p->scale[7], p->shift[7], Bf, B, Hs[4], Ws[4], 128, 128, 1, 0, st));
+  // merged 3x3 heads: [detector hidden | descriptor hidden]
+  GFC_TRY(gfc_conv3x3(Bf, p->wh, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
+  const int rows = B * Hs[4] * Ws[4];
+  // detector 1x1 -> 65 logits (into Bf), descriptor 1x1 -> desc_raw
+  GFC_TRY(gfc_linear(A, 512, 256, nullptr, 0, 0, p->wp, 256, p->bias_p, p->scale_p, p->shift_p, 1.f, nullptr, nullptr,
+                     nullptr, 0, Bf, 65, rows, 65, st));
+  GFC_TRY(gfc_linear(A + 256, 512, 256, nullptr, 0, 0, p->wd, 256, p->bias_d, p->scale_d, p->shift_d, 1.f, nullptr,
+                     nullptr, nullptr, 0, desc_raw, p->desc_dim, rows, p->desc_dim, st));
+  GFC_TRY(gfc_softmax_d2s(Bf, 65, B, Hs[4], Ws[4], heatmap, st));
+  return GFC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LightGlue forward
+// ---------------------------------------------------------------------------------------------
+struct LgPlan {
+  size_t R;
+  size_t x, qkv, ctx, msg, hbuf, cosb, sinb, z, stats, filt, tables, total;
+};
+
+static LgPlan lg_plan(int B, int M, int N) {
+  LgPlan p;
+  p.R = (size_t)B * (M + N);
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += gfc_align(bytes); return o; };
+  p.x = take(p.R * 256 * 4);
+  p.qkv = take(p.R * 768 * 4);
+  p.ctx = take(p.R * 256 * 4);
+  p.msg = take(p.R * 256 * 4);
+  p.hbuf = take(p.R * 512 * 4);
+  p.cosb = take(p.R * 64 * 4);
+  p.sinb = take(p.R * 64 * 4);
+  p.z = take(p.R * 4);
+  p.stats = take((size_t)2 * B * (M + N) * 4);
+  p.filt = take((size_t)B * (M + N) * 8);
+  p.tables = take((size_t)B * (2 * 4 * 2 + 2 + 2 + 4) * 4 + 256);
+  p.total = off;
+  return p;
+}
+
+extern "C" size_t gfc_lg_workspace_bytes(int B, int M, int N) {
+  if (B <= 0 || M <= 0 || N <= 0) return 0;
+  return lg_plan(B, M, N).total;
+}
+
+// tables: self problems [2B][4], cross problems [2B][4], row0 [2B], n [2B], sizes [2B][2]
+__global__ void lg_tables_kernel(int B, int M, int N, const float* size0, const float* size1, int* self_p,
+                                 int* cross_p, int* row0, int* nrow, float* sizes) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int r0 = b * M, r1 = B * M + b * N;
+  int* s = self_p + 4 * b;
+  s[0] = r0; s[1] = M; s[2] = r0; s[3] = M;
+  s = self_p + 4 * (B + b);
+  s[0] = r1; s[1] = N; s[2] = r1; s[3] = N;
+  int* c = cross_p + 4 * b;
+  c[0] = r0; c[1] = M; c[2] = r1; c[3] = N;
+  c = cross_p + 4 * (B + b);
+  c[0] = r1; c[1] = N; c[2] = r0; c[3] = M;
+  row0[b] = r0; nrow[b] = M;
+  row0[B + b] = r1; nrow[B + b] = N;
+  sizes[2 * b] = size0[2 * b]; sizes[2 * b + 1] = size0[2 * b + 1];
+  sizes[2 * (B + b)] = size1[2 * b]; sizes[2 * (B + b) + 1] = size1[2 * b + 1];
+}
+
+extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,
+                              const float* desc1, const float* size0, const float* size1, int B, int M, int N,
+                              float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1,
+                              float* log_assignment, float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes,
+                              void* stream) {
+  if (!p || !kpts0 || !kpts1 || !desc0 || !desc1 || !size0 || !size1 || !m0 || !m1 || !ms0 || !ms1 ||
+      !log_assignment || !ws)
+    return GFC_ERR_INVALID;
+  if (B <= 0 || M <= 0 || N <= 0 || p->n_layers <= 0 || p->n_layers > GFC_LG_MAX_LAYERS) return GFC_ERR_INVALID;
+  if (p->input_dim != 256 && (!p->input_proj_w || !p->input_proj_b || p->input_dim % 32)) return GFC_ERR_INVALID;
+  if (ws_bytes < gfc_lg_workspace_bytes(B, M, N)) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const LgPlan pl = lg_plan(B, M, N);
+  char* base = (char*)ws;
+  float* x = (float*)(base + pl.x);
+  float* qkv = (float*)(base + pl.qkv);
+  float* ctx = (float*)(base + pl.ctx);
+  float* msg = (float*)(base + pl.msg);
+  float* hbuf = (float*)(base + pl.hbuf);
+  float* cosb = (float*)(base + pl.cosb);
+  float* sinb = (float*)(base + pl.sinb);
+  float* z = (float*)(base + pl.z);
+  float* stats = (float*)(base + pl.stats);
+  void* filt = (void*)(base + pl.filt);
+  int* self_p = (int*)(base + pl.tables);
+  int* cross_p = self_p + 8 * B;
+  int* row0 = cross_p + 8 * B;
+  int* nrow = row0 + 2 * B;
+  float* sizes = (float*)(nrow + 2 * B);
+  const int R = (int)pl.R, R0 = B * M, R1 = B * N;
+  const int D = 256;
+
+  hipLaunchKernelGGL(lg_tables_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, M, N, size0, size1, self_p, cross_p,
+                     row0, nrow, sizes);
+  GFC_LAUNCH_CHECK();
+
+  // keypoints of both sides packed after each other for the rotary tables
+  // (reuse msg as scratch: [R][2] floats)
+  if (hipMemcpyAsync(msg, kpts0, (size_t)R0 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
+  if (hipMemcpyAsync(msg + (size_t)R0 * 2, kpts1, (size_t)R1 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return GFC_ERR_LAUNCH;
+  GFC_TRY(gfc_lg_posenc(msg, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, cosb, sinb, st));
+
+  // descriptors -> x (input_proj when input_dim != 256, lightglue.py:352-355,464-465)
+  if (p->input_dim == D) {
+    if (hipMemcpyAsync(x, desc0, (size_t)R0 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
+    if (hipMemcpyAsync(x + (size_t)R0 * D, desc1, (size_t)R1 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return GFC_ERR_LAUNCH;
+  } else {
+    const int Din = p->input_dim;
+    GFC_TRY(gfc_linear(desc0, Din, Din, nullptr, 0, 0, p->input_proj_w, Din, p->input_proj_b, nullptr, nullptr, 1.f,
+                       nullptr, nullptr, nullptr, 0, x, D, R0, D, st));
+    GFC_TRY(gfc_linear(desc1, Din, Din, nullptr, 0, 0, p->input_proj_w, Din, p->input_proj_b, nullptr, nullptr, 1.f,
+                       nullptr, nullptr, nullptr, 0, x + (size_t)R0 * D, D, R1, D, st));
+  }
+
+  const int maxn = M > N ? M : N;
+  for (int l = 0; l < p->n_layers; ++l) {
+    // ---- self block (lightglue.py:151-164) ----
+    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, nullptr, 1.f, nullptr, cosb, sinb,
+                       512, qkv, 768, R, 768, st));
+    GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, 2 * B, maxn, 4, 0.125f, st));
+    GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->s_out_w[l], D, p->s_out_b[l], nullptr, nullptr, 1.f, nullptr,
+                       nullptr, nullptr, 0, msg, D, R, D, st));
+    GFC_TRY(gfc_linear(x, D, D, msg, D, D, p->s_ffn0_w[l], 512, p->s_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
+                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
+    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->s_ln_g[l], p->s_ln_b[l], st));
+    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], nullptr, nullptr, 1.f, x,
+                       nullptr, nullptr, 0, x, D, R, D, st));
+    // ---- cross block (lightglue.py:193-222) ----
+    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, 1.f, nullptr, nullptr,
+                       nullptr, 0, qkv, 512, R, 512, st));
+    GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, 2 * B, maxn, 4, 0.125f, st));
+    GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,
+                       nullptr, nullptr, 0, msg, D, R, D, st));
+    GFC_TRY(gfc_linear(x, D, D, msg, D, D, p->c_ffn0_w[l], 512, p->c_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
+                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
+    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->c_ln_g[l], p->c_ln_b[l], st));
+    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], nullptr, nullptr, 1.f, x,
+                       nullptr, nullptr, 0, x, D, R, D, st));
+  }
+
+  if (ref_desc0 && hipMemcpyAsync(ref_desc0, x, (size_t)R0 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return GFC_ERR_LAUNCH;
+  if (ref_desc1 &&
+      hipMemcpyAsync(ref_desc1, x + (size_t)R0 * D, (size_t)R1 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+    return GFC_ERR_LAUNCH;
+
+  // ---- assignment (lightglue.py:279-288) + filter (lightglue.py:294-319) ----
+  float* md = ctx;
+  GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->final_proj_w, D, p->final_proj_b, nullptr, nullptr, 0.25f, nullptr,
+                     nullptr, nullptr, 0, md, D, R, D, st));
+  GFC_TRY(gfc_rowdot256(x, D, R, p->matchability_w, p->matchability_b, z, st));
+  GFC_TRY(gfc_batched_nt(md, D, (long long)M * D, md + (size_t)R0 * D, D, (long long)N * D, log_assignment, N + 1,
+                         (long long)(M + 1) * (N + 1), M, N, D, B, st));
+  GFC_TRY(gfc_assign_inplace(log_assignment, z, z + R0, B, M, N, stats, st));
+  GFC_TRY(gfc_lg_filter_matches(log_assignment, B, M, N, threshold, m0, m1, ms0, ms1, filt, (size_t)B * (M + N) * 8,
+                                st));
+  return GFC_OK;
+}

@@ -1,0 +1,148 @@
+// Flash-style multi-head attention on fp32 MFMA (head_dim 64), score matrix never materialised.
+//
+// Replaces F.scaled_dot_product_attention in SelfBlock (reference
+// gluefactory/models/matchers/lightglue.py:119-122,160-162) and the bidirectional cross attention
+// of CrossBlock (lightglue.py:207-217: softmax over rows and over columns of the same similarity
+// matrix), issued as two problems of one launch.
+//
+// Layout: one workgroup = 4 waves = 128 query rows of one (problem, head); each wave owns 32
+// queries.  Keys/values stream through LDS in tiles of 64.  Per 32-key half tile a wave computes
+//     S^T[key][q] = K . Q^T            A = K rows (LDS, ds_read_b128), B = Q (registers)
+// so that the accumulator holds, for lane (q = lane&31, half h), the 16 keys r -> (r&3)+8(r>>2)+4h.
+// Softmax statistics are then lane-local (+ one exchange with lane^32), and the accumulator
+// registers are *already* the B operand of
+//     O^T[d][q] += V^T[d][key] . P^T[key][q]      A = V[key][d] (LDS, ds_read_b32), B = P register r
+// -- no transpose, no LDS round trip for P.  O^T keeps q on the lane, so the running rescale is a
+// per-lane scalar multiply.
+#include "common.h"
+
+#define AQ 128   // queries per workgroup
+#define AK 64    // keys per LDS tile
+#define AD 64    // head dim
+#define AKLD (AD + 4)
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ Q, int ldq,
+                                                           const float* __restrict__ Kp, int ldk,
+                                                           const float* __restrict__ V, int ldv,
+                                                           float* __restrict__ O, int ldo,
+                                                           const int4* __restrict__ problems, float scale_log2e) {
+  __shared__ __attribute__((aligned(16))) float Ks[AK * AKLD];
+  __shared__ __attribute__((aligned(16))) float Vs[AK * AD];
+
+  const int4 pb = problems[blockIdx.z];
+  const int q_row0 = pb.x, nq = pb.y, kv_row0 = pb.z, nk = pb.w;
+  const int qt0 = blockIdx.x * AQ;
+  if (qt0 >= nq) return;  // uniform for the whole workgroup
+  const int head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+
+  // ---- Q fragments: lane (q, h) keeps Q[q][8g + 4h + s], g = 0..7, s = 0..3 ----
+  const int q = qt0 + wave * 32 + l31;
+  const int qc = min(q, nq - 1);
+  float4 qf[8];
+  {
+    const float* qp = Q + (size_t)(q_row0 + qc) * ldq + head * AD + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const float4*>(qp + 8 * g);
+  }
+
+  f32x16 o[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (nk + AK - 1) / AK;
+  for (int kt = 0; kt < ntiles; ++kt) {
+    // ---- stage K and V tiles (clamped rows; masked below) ----
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int idx = tid + 256 * i;
+      int key = idx >> 4, c4 = idx & 15;
+      int kr = kv_row0 + min(kt * AK + key, nk - 1);
+      float4 kv = *reinterpret_cast<const float4*>(Kp + (size_t)kr * ldk + head * AD + c4 * 4);
+      float4 vv = *reinterpret_cast<const float4*>(V + (size_t)kr * ldv + head * AD + c4 * 4);
+      *reinterpret_cast<float4*>(Ks + key * AKLD + c4 * 4) = kv;
+      *reinterpret_cast<float4*>(Vs + key * AD + c4 * 4) = vv;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int key0 = kt * AK + half * 32;
+      if (key0 >= nk) break;  // uniform
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const float* kp = Ks + (half * 32 + l31) * AKLD + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) {
+        float4 kf = *reinterpret_cast<const float4*>(kp + 8 * g);
+        s = mfma32(kf.x, qf[g].x, s);
+        s = mfma32(kf.y, qf[g].y, s);
+        s = mfma32(kf.z, qf[g].z, s);
+        s = mfma32(kf.w, qf[g].w, s);
+      }
+      // mask the tail keys, running max
+      float mx = -INFINITY;
+      if (key0 + 32 > nk) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (key0 + acc_row(r, h) >= nk) s[r] = -INFINITY;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = exp2f((m_run - m_new) * scale_log2e);
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s[r] = exp2f((s[r] - m_new) * scale_log2e);
+        rs += s[r];
+      }
+      rs += __shfl_xor(rs, 32);
+      l_run = l_run * alpha + rs;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+      // O^T += V^T P^T
+      const float* vp = Vs + (half * 32 + 4 * h) * AD + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int krow = (r & 3) + 8 * (r >> 2);
+        float v0 = vp[krow * AD];
+        float v1 = vp[krow * AD + 32];
+        o[0] = mfma32(v0, s[r], o[0]);
+        o[1] = mfma32(v1, s[r], o[1]);
+      }
+    }
+  }
+
+  // ---- normalise and store: lane holds O[q][db*32 + 8*(r>>2) + 4h + (r&3)] ----
+  if (q < nq) {
+    const float inv = 1.f / l_run;
+    float* op = O + (size_t)(q_row0 + q) * ldo + head * AD + 4 * h;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        float4 v = make_float4(o[db][4 * g] * inv, o[db][4 * g + 1] * inv, o[db][4 * g + 2] * inv,
+                               o[db][4 * g + 3] * inv);
+        *reinterpret_cast<float4*>(op + db * 32 + 8 * g) = v;
+      }
+  }
+}
+
+extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                             int ldo, const int32_t* problems, int n_problems, int max_nq, int heads, float scale,
+                             void* stream) {
+  if (!Q || !K || !V || !O || !problems || n_problems <= 0 || max_nq <= 0 || heads <= 0) return GFC_ERR_INVALID;
+  if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return GFC_ERR_INVALID;
+  dim3 grid((max_nq + AQ - 1) / AQ, heads, n_problems);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, Q, ldq, K, ldk, V, ldv, O, ldo,
+                     reinterpret_cast<const int4*>(problems), scale * 1.4426950408889634f);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

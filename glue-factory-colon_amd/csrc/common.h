@@ -1,0 +1,37 @@
+// Shared device helpers for the gfx950 kernels (wave64, fp32 MFMA).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gfc_amd.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// D(32x32) += A(32x2) * B(2x32).  Lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+// D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31] lives in register r of lane l.
+// Exact fp32 (a k-ordered fmaf chain), 64 cycles per SIMD.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Row of accumulator register r for lane half h in a 32x32 tile.
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+#define GFC_LAUNCH_CHECK()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return GFC_ERR_LAUNCH; \
+  } while (0)
+
+static inline size_t gfc_align(size_t x) { return (x + 255) & ~(size_t)255; }

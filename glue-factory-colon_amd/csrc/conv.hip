@@ -1,0 +1,306 @@
+// 3x3 convolutions of the SuperPoint encoder as fp32-MFMA implicit GEMM (NHWC).
+//
+// Replaces: VGGBlock conv -> ReLU -> BatchNorm(eval) [+ MaxPool2d(2,2)]
+//           (reference gluefactory/models/extractors/superpoint_open.py:61-77,100-108)
+//           and conv -> ReLU [+ pool] of gluefactory_nonfree/superpoint.py:214-224.
+//
+// One workgroup (4 waves) computes a 16x16 pixel tile x 64 output channels.  The input
+// halo tile (18x18 pixels x 32 channels) sits in LDS; the A operand of tap (dy,dx) is the
+// same LDS image read at a shifted pixel offset, so no im2col buffer exists.  K is walked
+// as (channel chunk of 32) x (9 taps); per step the 64x32 weight slice is double-buffered
+// in LDS and prefetched through registers while the MFMAs of the current step run.
+// Each lane reads 4 consecutive k with one ds_read_b128; MFMA s of a group pairs k = 4h+s of
+// both lane halves (any k order is a valid dot product as long as A and B agree).
+#include "common.h"
+
+#define CT 16              // output tile edge (pixels)
+#define CH (CT + 2)        // halo tile edge
+#define CKC 32             // channels per chunk
+#define CLD (CKC + 4)      // LDS row stride in floats (bank-conflict padding, keeps 16B alignment)
+#define CNB 64             // output channels per workgroup
+
+__global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  int total = cout * cin * 9;
+  if (i >= total) return;
+  int ci = i % cin;
+  int co = (i / cin) % cout;
+  int tap = i / (cin * cout);
+  out[i] = w[((size_t)co * cin + ci) * 9 + tap];
+}
+
+// (image * [0.299, 0.587, 0.114]).sum(1): superpoint_open.py:128-130
+__global__ void rgb_to_gray_kernel(const float* __restrict__ img, float* __restrict__ out, int B, long long hw) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * hw) return;
+  long long b = i / hw, p = i % hw;
+  const float* s = img + b * 3 * hw + p;
+  float v = s[0] * 0.299f;
+  v += s[hw] * 0.587f;
+  v += s[2 * hw] * 0.114f;
+  out[i] = v;
+}
+
+// First layer, cin = 1: direct VALU convolution (0.7 % of the FLOPs, bound by the 64-channel write).
+// 4 threads per pixel, 16 channels each; w [9][64].
+__global__ __launch_bounds__(256) void conv3x3_c1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, float* __restrict__ y, int B,
+                                                         int H, int W, int relu) {
+  __shared__ float ws[9 * 64 + 3 * 64];
+  for (int i = threadIdx.x; i < 9 * 64; i += 256) ws[i] = w[i];
+  if (threadIdx.x < 64) {
+    ws[576 + threadIdx.x] = bias[threadIdx.x];
+    ws[640 + threadIdx.x] = scale ? scale[threadIdx.x] : 1.f;
+    ws[704 + threadIdx.x] = shift ? shift[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long pix = t >> 2;
+  int cg = (int)(t & 3) * 16;
+  if (pix >= (long long)B * H * W) return;
+  int px = (int)(pix % W);
+  int py = (int)((pix / W) % H);
+  const float* xb = x + (pix - (long long)py * W - px);
+  float v[9];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      int yy = py + dy - 1, xx = px + dx - 1;
+      v[dy * 3 + dx] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? xb[(long long)yy * W + xx] : 0.f;
+    }
+  float* yo = y + pix * 64 + cg;
+#pragma unroll
+  for (int c4 = 0; c4 < 4; ++c4) {
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int c = cg + c4 * 4 + j;
+      float a = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) a = fmaf(v[tp], ws[tp * 64 + c], a);
+      a += ws[576 + c];
+      if (relu) a = fmaxf(a, 0.f);
+      o[j] = a * ws[640 + c] + ws[704 + c];
+    }
+    *reinterpret_cast<float4*>(yo + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+struct ConvArgs {
+  const float* x;
+  const float* w;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  float* y;
+  int B, H, W, cin, cout, relu;
+  int tiles_x, tiles_y;
+};
+
+template <bool POOL>
+__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* in_s = smem;                   // [CH*CH][CLD]
+  float* w_s = smem + CH * CH * CLD;    // [2][CNB][CLD]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int l31 = lane & 31;
+  const int h = lane >> 5;
+
+  int bid = blockIdx.x;
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int nb = blockIdx.y;
+  const int x0 = tx * CT, y0 = ty * CT;
+  const int cin = a.cin;
+  const int nchunks = cin / CKC;
+  const int nsteps = nchunks * 9;
+
+  const float* xin = a.x + (size_t)b * a.H * a.W * cin;
+  const float* wbase = a.w + (size_t)nb * CNB * cin;  // + tap*cout*cin + co*cin + chunk*32
+
+  // ---- staging (register prefetch).  Macros, not lambdas: the prefetch registers must stay in
+  // VGPRs (a by-reference lambda capture demoted them to a private-memory array). ----
+  float4 wreg0, wreg1;
+  float4 ireg[11];
+  const int st_co = tid >> 3, st_c4 = (tid & 7) * 4;  // weight rows st_co, st_co + 32
+#define CONV_LOAD_W(step_)                                                                  \
+  do {                                                                                      \
+    const int ch_ = (step_) / 9, tp_ = (step_) - ch_ * 9;                                   \
+    const float* src_ = wbase + (size_t)tp_ * a.cout * cin + ch_ * CKC + st_c4;             \
+    wreg0 = *reinterpret_cast<const float4*>(src_ + (size_t)st_co * cin);                   \
+    wreg1 = *reinterpret_cast<const float4*>(src_ + (size_t)(st_co + 32) * cin);            \
+  } while (0)
+#define CONV_STORE_W(buf_)                                                                  \
+  do {                                                                                      \
+    float* dst_ = w_s + (buf_) * CNB * CLD + st_co * CLD + st_c4;                           \
+    *reinterpret_cast<float4*>(dst_) = wreg0;                                               \
+    *reinterpret_cast<float4*>(dst_ + 32 * CLD) = wreg1;                                    \
+  } while (0)
+#define CONV_LOAD_IN(chunk_)                                                                \
+  _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                       \
+    const int idx_ = tid + 256 * i_;                                                        \
+    const int p_ = idx_ >> 3;                                                               \
+    const int gy_ = y0 - 1 + p_ / CH, gx_ = x0 - 1 + p_ % CH;                               \
+    float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
+    if (idx_ < CH * CH * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W)               \
+      v_ = *reinterpret_cast<const float4*>(xin + ((size_t)gy_ * a.W + gx_) * cin + (chunk_) * CKC + st_c4); \
+    ireg[i_] = v_;                                                                          \
+  }
+#define CONV_STORE_IN()                                                                     \
+  _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                       \
+    const int idx_ = tid + 256 * i_;                                                        \
+    if (idx_ < CH * CH * 8) *reinterpret_cast<float4*>(in_s + (idx_ >> 3) * CLD + st_c4) = ireg[i_]; \
+  }
+
+  // this lane's two pixel rows in the halo image (tap (0,0) corner), and weight rows
+  int a_off[2], b_off[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    int py = 4 * wave + 2 * mt + (l31 >> 4), px = l31 & 15;
+    a_off[mt] = (py * CH + px) * CLD + 4 * h;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) b_off[nt] = (nt * 32 + l31) * CLD + 4 * h;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  CONV_LOAD_IN(0);
+  CONV_LOAD_W(0);
+  CONV_STORE_IN();
+  CONV_STORE_W(0);
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const int chunk = step / 9, tap = step - chunk * 9;
+    const bool has_next = step + 1 < nsteps;
+    const bool new_chunk = has_next && tap == 8;
+    if (has_next) CONV_LOAD_W(step + 1);
+    if (new_chunk) { CONV_LOAD_IN(chunk + 1); }
+
+    const int dy = tap / 3, dx = tap - dy * 3;
+    const float* ap = in_s + (dy * CH + dx) * CLD;
+    const float* bp = w_s + (step & 1) * CNB * CLD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float4 af[2], bf[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const float4*>(ap + a_off[mt] + 8 * g);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const float4*>(bp + b_off[nt] + 8 * g);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
+        }
+    }
+    if (has_next) CONV_STORE_W((step + 1) & 1);
+    if (new_chunk) {
+      __syncthreads();  // every wave is done reading the old input chunk
+      CONV_STORE_IN();
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, ReLU, per-channel affine (BN), optional 2x2 max-pool ----
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int co = nb * CNB + nt * 32 + l31;
+    const float bi = a.bias[co];
+    const float sc = a.scale ? a.scale[co] : 1.f;
+    const float sh = a.shift ? a.shift[co] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float t = acc[mt][nt][r] + bi;
+        if (a.relu) t = fmaxf(t, 0.f);
+        v[r] = t * sc + sh;
+      }
+      if (!POOL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int i = acc_row(r, h);
+          int gy = y0 + 4 * wave + 2 * mt + (i >> 4), gx = x0 + (i & 15);
+          if (gy < a.H && gx < a.W) a.y[(((size_t)b * a.H + gy) * a.W + gx) * a.cout + co] = v[r];
+        }
+      } else {
+        const int Ho = a.H >> 1, Wo = a.W >> 1;
+        const int oy = (y0 >> 1) + 2 * wave + mt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int r = 2 * q;  // r, r+1: horizontal neighbours; r+8, r+9: the row below
+          float m = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
+          int pxl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;  // even column inside the 16-wide tile
+          int ox = (x0 >> 1) + (pxl >> 1);
+          if (oy < Ho && ox < Wo) a.y[(((size_t)b * Ho + oy) * Wo + ox) * a.cout + co] = m;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int gfc_pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, void* stream) {
+  if (!w_oihw || !w_packed || cout <= 0 || cin <= 0) return GFC_ERR_INVALID;
+  int total = cout * cin * 9;
+  hipLaunchKernelGGL(pack_conv3x3_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, w_oihw,
+                     w_packed, cout, cin);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+int gfc_rgb_to_gray(const float* img, float* out, int B, int H, int W, hipStream_t stream) {
+  long long hw = (long long)H * W;
+  long long total = hw * B;
+  hipLaunchKernelGGL(rgb_to_gray_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, img, out, B, hw);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* bias, const float* scale,
+                           const float* shift, float* y, int B, int H, int W, int cin, int cout, int relu, int pool,
+                           void* stream) {
+  if (!x || !w_packed || !bias || !y || B <= 0 || H <= 0 || W <= 0) return GFC_ERR_INVALID;
+  if ((scale == nullptr) != (shift == nullptr)) return GFC_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (cin == 1) {
+    if (cout != 64 || pool) return GFC_ERR_UNSUPPORTED;
+    long long threads = (long long)B * H * W * 4;
+    hipLaunchKernelGGL(conv3x3_c1_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, x, w_packed, bias,
+                       scale, shift, y, B, H, W, relu);
+    GFC_LAUNCH_CHECK();
+    return GFC_OK;
+  }
+  if (cin % CKC != 0 || cout % CNB != 0) return GFC_ERR_UNSUPPORTED;
+  ConvArgs a;
+  a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
+  a.tiles_x = (W + CT - 1) / CT;
+  a.tiles_y = (H + CT - 1) / CT;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * B), cout / CNB);
+  size_t lds = (size_t)(CH * CH * CLD + 2 * CNB * CLD) * sizeof(float);
+  if (pool)
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, grid, dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, grid, dim3(256), lds, st, a);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

@@ -1,0 +1,317 @@
+// LightGlue: positional encoding, LayerNorm+GELU, matchability, dual log-softmax assignment and
+// mutual-argmax match filtering.  HBM-bound row/column reductions on wavefronts.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// normalize_keypoints + LearnableFourierPositionalEncoding (lightglue.py:28-40,53-66).
+// cos/sin [rows][64]: value of frequency f stored at 2f and 2f+1 (repeat_interleave(2)).
+// ------------------------------------------------------------------------------------------
+__global__ void posenc_kernel(const float* __restrict__ kpts, const float* __restrict__ sizes,
+                              const int* __restrict__ row0, const int* __restrict__ nrows,
+                              const float* __restrict__ wr, float* __restrict__ cos_out, float* __restrict__ sin_out) {
+  const int img = blockIdx.y;
+  const int n = nrows[img];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (row, freq)
+  const int i = t >> 5, f = t & 31;
+  if (i >= n) return;
+  const size_t row = (size_t)row0[img] + i;
+  const float sw = sizes[2 * img], sh = sizes[2 * img + 1];
+  const float half_extent = fmaxf(sw, sh) / 2.f;
+  const float kx = (kpts[2 * row] - sw / 2.f) / half_extent;
+  const float ky = (kpts[2 * row + 1] - sh / 2.f) / half_extent;
+  float p = kx * wr[2 * f];
+  p += ky * wr[2 * f + 1];
+  const float c = cosf(p), s = sinf(p);
+  *reinterpret_cast<float2*>(cos_out + row * 64 + 2 * f) = make_float2(c, c);
+  *reinterpret_cast<float2*>(sin_out + row * 64 + 2 * f) = make_float2(s, s);
+}
+
+extern "C" int gfc_lg_posenc(const float* kpts, const float* sizes, const int32_t* row0, const int32_t* n,
+                             int n_images, int max_n, const float* wr, float* cos_out, float* sin_out, void* stream) {
+  if (!kpts || !sizes || !row0 || !n || !wr || !cos_out || !sin_out || n_images <= 0 || max_n <= 0) return GFC_ERR_INVALID;
+  dim3 grid((max_n * 32 + 255) / 256, n_images);
+  hipLaunchKernelGGL(posenc_kernel, grid, dim3(256), 0, (hipStream_t)stream, kpts, sizes, row0, n, wr, cos_out, sin_out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm(512, eps 1e-5) + GELU(erf), in place; one wave per row (lightglue.py:143-148).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__ x, int ld, int rows,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* p = x + (size_t)row * ld;
+  float4 v[2];
+  v[0] = *reinterpret_cast<const float4*>(p + lane * 4);
+  v[1] = *reinterpret_cast<const float4*>(p + 256 + lane * 4);
+  float s = (v[0].x + v[0].y) + (v[0].z + v[0].w) + (v[1].x + v[1].y) + (v[1].z + v[1].w);
+  const float mean = wave_sum(s) * (1.f / 512.f);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+    q += a * a + b * b + c * c + d * d;
+  }
+  const float var = wave_sum(q) * (1.f / 512.f);
+  const float rstd = 1.f / sqrtf(var + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c0 = i * 256 + lane * 4;
+    const float4 g = *reinterpret_cast<const float4*>(gamma + c0);
+    const float4 bb = *reinterpret_cast<const float4*>(beta + c0);
+    float y[4] = {(v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
+                  (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) y[j] = 0.5f * y[j] * (1.f + erff(y[j] * 0.70710678118654752440f));
+    *reinterpret_cast<float4*>(p + c0) = make_float4(y[0], y[1], y[2], y[3]);
+  }
+}
+
+extern "C" int gfc_layernorm_gelu(float* x, int ld, int rows, int width, const float* gamma, const float* beta,
+                                  void* stream) {
+  if (!x || !gamma || !beta || rows <= 0 || ld % 4) return GFC_ERR_INVALID;
+  if (width != 512) return GFC_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(layernorm_gelu_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ld, rows, gamma,
+                     beta);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// matchability logit z[row] = x[row,:256] . w + b    (lightglue.py:286-287)
+__global__ __launch_bounds__(256) void rowdot256_kernel(const float* __restrict__ x, int ld, int rows,
+                                                        const float* __restrict__ w, const float* __restrict__ bias,
+                                                        float* __restrict__ z) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4 a = *reinterpret_cast<const float4*>(x + (size_t)row * ld + lane * 4);
+  const float4 b = *reinterpret_cast<const float4*>(w + lane * 4);
+  float s = wave_sum(a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w);
+  if (lane == 0) z[row] = s + bias[0];
+}
+
+int gfc_rowdot256(const float* x, int ld, int rows, const float* w, const float* bias, float* z, hipStream_t st) {
+  hipLaunchKernelGGL(rowdot256_kernel, dim3((rows + 3) / 4), dim3(256), 0, st, x, ld, rows, w, bias, z);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sigmoid_log_double_softmax (lightglue.py:257-269):
+//   S[i,j] = log_softmax_j(sim)[i,j] + log_softmax_i(sim)[i,j] + logsig(z0_i) + logsig(z1_j)
+//   S[i,N] = logsig(-z0_i),  S[M,j] = logsig(-z1_j),  S[M,N] = 0
+// log_softmax(x) = (x - max) - log(sum(exp(x - max))).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float logsigmoid(float x) {
+  // F.logsigmoid: min(x, 0) - log1p(exp(-|x|))
+  return fminf(x, 0.f) - log1pf(expf(-fabsf(x)));
+}
+
+// rows: one wave per row.  stats[0] = max, stats[1] = log(sum exp)
+__global__ __launch_bounds__(256) void lse_rows_kernel(const float* __restrict__ sim, long long stride_b, int ld,
+                                                       int M, int N, float* __restrict__ rmax,
+                                                       float* __restrict__ rlog) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= M) return;
+  const float* p = sim + b * stride_b + (size_t)i * ld;
+  float m = -INFINITY;
+  for (int j = lane; j < N; j += 64) m = fmaxf(m, p[j]);
+  m = wave_max(m);
+  float s = 0.f;
+  for (int j = lane; j < N; j += 64) s += expf(p[j] - m);
+  s = wave_sum(s);
+  if (lane == 0) {
+    rmax[(size_t)b * M + i] = m;
+    rlog[(size_t)b * M + i] = logf(s);
+  }
+}
+
+// columns: block = 32 columns x 8 row groups, online (max, sum) per thread, LDS combine
+__global__ __launch_bounds__(256) void lse_cols_kernel(const float* __restrict__ sim, long long stride_b, int ld,
+                                                       int M, int N, float* __restrict__ cmax,
+                                                       float* __restrict__ clog) {
+  __shared__ float sm[8][32], ss[8][32];
+  const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx, b = blockIdx.y;
+  const float* p = sim + b * stride_b;
+  float m = -INFINITY, s = 0.f;
+  if (j < N)
+    for (int i = rg; i < M; i += 8) {
+      float v = p[(size_t)i * ld + j];
+      if (v > m) { s = s * expf(m - v) + 1.f; m = v; } else { s += expf(v - m); }
+    }
+  sm[rg][cx] = m;
+  ss[rg][cx] = s;
+  __syncthreads();
+  if (rg == 0 && j < N) {
+    float mm = -INFINITY;
+    for (int g = 0; g < 8; ++g) mm = fmaxf(mm, sm[g][cx]);
+    float t = 0.f;
+    for (int g = 0; g < 8; ++g) t += (ss[g][cx] > 0.f) ? ss[g][cx] * expf(sm[g][cx] - mm) : 0.f;
+    cmax[(size_t)b * N + j] = mm;
+    clog[(size_t)b * N + j] = logf(t);
+  }
+}
+
+__global__ __launch_bounds__(256) void assign_finalize_kernel(const float* __restrict__ sim, long long stride_sim,
+                                                              int lds, const float* __restrict__ z0,
+                                                              const float* __restrict__ z1, int M, int N,
+                                                              const float* __restrict__ rmax,
+                                                              const float* __restrict__ rlog,
+                                                              const float* __restrict__ cmax,
+                                                              const float* __restrict__ clog, float* __restrict__ out) {
+  // grid: (ceil((N+1)/256), M+1, B).  out[b][i][j], ld = N+1.  May run in place (sim == out, lds == N+1):
+  // every element is read and written by the same thread.
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j > N) return;
+  float* o = out + ((size_t)b * (M + 1) + i) * (N + 1) + j;
+  float v;
+  if (i < M && j < N) {
+    const float x = sim[b * stride_sim + (size_t)i * lds + j];
+    const float s0 = (x - rmax[(size_t)b * M + i]) - rlog[(size_t)b * M + i];
+    const float s1 = (x - cmax[(size_t)b * N + j]) - clog[(size_t)b * N + j];
+    const float cert = logsigmoid(z0[(size_t)b * M + i]) + logsigmoid(z1[(size_t)b * N + j]);
+    v = (s0 + s1) + cert;
+  } else if (i < M) {
+    v = logsigmoid(-z0[(size_t)b * M + i]);
+  } else if (j < N) {
+    v = logsigmoid(-z1[(size_t)b * N + j]);
+  } else {
+    v = 0.f;
+  }
+  *o = v;
+}
+
+// In-place variant used by gfc_lg_forward: sim was written by the GEMM straight into the inner block of
+// the [M+1][N+1] output (ld = N+1).
+int gfc_assign_inplace(float* scores, const float* z0, const float* z1, int B, int M, int N, float* stats,
+                       hipStream_t st) {
+  float* rmax = stats;
+  float* rlog = rmax + (size_t)B * M;
+  float* cmax = rlog + (size_t)B * M;
+  float* clog = cmax + (size_t)B * N;
+  const long long sb = (long long)(M + 1) * (N + 1);
+  hipLaunchKernelGGL(lse_rows_kernel, dim3((M + 3) / 4, B), dim3(256), 0, st, scores, sb, N + 1, M, N, rmax, rlog);
+  hipLaunchKernelGGL(lse_cols_kernel, dim3((N + 31) / 32, B), dim3(256), 0, st, scores, sb, N + 1, M, N, cmax, clog);
+  hipLaunchKernelGGL(assign_finalize_kernel, dim3((N + 1 + 255) / 256, M + 1, B), dim3(256), 0, st, scores, sb, N + 1,
+                     z0, z1, M, N, rmax, rlog, cmax, clog, scores);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+extern "C" int gfc_lg_log_assignment(const float* sim, const float* z0, const float* z1, int B, int M, int N,
+                                     float* out, void* ws, size_t ws_bytes, void* stream) {
+  if (!sim || !z0 || !z1 || !out || !ws || B <= 0 || M <= 0 || N <= 0) return GFC_ERR_INVALID;
+  if (ws_bytes < (size_t)2 * B * (M + N) * sizeof(float)) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* rmax = (float*)ws;
+  float* rlog = rmax + (size_t)B * M;
+  float* cmax = rlog + (size_t)B * M;
+  float* clog = cmax + (size_t)B * N;
+  const long long sb = (long long)M * N;
+  hipLaunchKernelGGL(lse_rows_kernel, dim3((M + 3) / 4, B), dim3(256), 0, st, sim, sb, N, M, N, rmax, rlog);
+  hipLaunchKernelGGL(lse_cols_kernel, dim3((N + 31) / 32, B), dim3(256), 0, st, sim, sb, N, M, N, cmax, clog);
+  hipLaunchKernelGGL(assign_finalize_kernel, dim3((N + 1 + 255) / 256, M + 1, B), dim3(256), 0, st, sim, sb, N, z0, z1,
+                     M, N, rmax, rlog, cmax, clog, out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// filter_matches (lightglue.py:294-319).  Integer outputs are bit-exact: max / argmax over the
+// inner [M,N] block with first-index tie break (torch.max on CPU), mutual check by gather.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowargmax_kernel(const float* __restrict__ sc, int M, int N,
+                                                        float* __restrict__ vmax, int* __restrict__ imax) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= M) return;
+  const float* p = sc + ((size_t)b * (M + 1) + i) * (N + 1);
+  float m = -INFINITY;
+  int idx = 0x7FFFFFFF;
+  for (int j = lane; j < N; j += 64) {
+    float v = p[j];
+    if (v > m || idx == 0x7FFFFFFF) { m = v; idx = j; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(m, o);
+    int oi = __shfl_xor(idx, o);
+    if (om > m || (om == m && oi < idx)) { m = om; idx = oi; }
+  }
+  if (lane == 0) { vmax[(size_t)b * M + i] = m; imax[(size_t)b * M + i] = idx; }
+}
+
+__global__ __launch_bounds__(256) void colargmax_kernel(const float* __restrict__ sc, int M, int N,
+                                                        int* __restrict__ imax) {
+  __shared__ float sm[8][32];
+  __shared__ int si[8][32];
+  const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx, b = blockIdx.y;
+  const float* p = sc + (size_t)b * (M + 1) * (N + 1);
+  float m = -INFINITY;
+  int idx = 0x7FFFFFFF;
+  if (j < N)
+    for (int i = rg; i < M; i += 8) {
+      float v = p[(size_t)i * (N + 1) + j];
+      if (v > m || idx == 0x7FFFFFFF) { m = v; idx = i; }
+    }
+  sm[rg][cx] = m;
+  si[rg][cx] = idx;
+  __syncthreads();
+  if (rg == 0 && j < N) {
+    for (int g = 1; g < 8; ++g) {
+      float om = sm[g][cx];
+      int oi = si[g][cx];
+      if (om > m || (om == m && oi < idx)) { m = om; idx = oi; }
+    }
+    imax[(size_t)b * N + j] = idx;
+  }
+}
+
+__global__ void mutual_kernel(const float* __restrict__ max0, const int* __restrict__ i0, const int* __restrict__ i1,
+                              int M, int N, float th, long long* __restrict__ m0, long long* __restrict__ m1,
+                              float* __restrict__ ms0, float* __restrict__ ms1) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int* a0 = i0 + (size_t)b * M;
+  const int* a1 = i1 + (size_t)b * N;
+  const float* mx = max0 + (size_t)b * M;
+  if (t < M) {
+    const int j = a0[t];
+    const bool mutual = a1[j] == t;
+    const float s = mutual ? expf(mx[t]) : 0.f;
+    ms0[(size_t)b * M + t] = s;
+    m0[(size_t)b * M + t] = (mutual && s > th) ? (long long)j : -1ll;
+  }
+  if (t < N) {
+    const int i = a1[t];
+    const bool mutual1 = a0[i] == t;
+    const bool mutual0 = a1[a0[i]] == i;
+    const float s0 = mutual0 ? expf(mx[i]) : 0.f;
+    ms1[(size_t)b * N + t] = mutual1 ? s0 : 0.f;
+    m1[(size_t)b * N + t] = (mutual1 && mutual0 && s0 > th) ? (long long)i : -1ll;
+  }
+}
+
+extern "C" int gfc_lg_filter_matches(const float* scores, int B, int M, int N, float threshold, int64_t* m0,
+                                     int64_t* m1, float* ms0, float* ms1, void* ws, size_t ws_bytes, void* stream) {
+  if (!scores || !m0 || !m1 || !ms0 || !ms1 || !ws || B <= 0 || M <= 0 || N <= 0) return GFC_ERR_INVALID;
+  if (ws_bytes < (size_t)B * (M + N) * 8) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  float* max0 = (float*)ws;
+  int* i0 = (int*)(max0 + (size_t)B * M);
+  int* i1 = i0 + (size_t)B * M;
+  hipLaunchKernelGGL(rowargmax_kernel, dim3((M + 3) / 4, B), dim3(256), 0, st, scores, M, N, max0, i0);
+  hipLaunchKernelGGL(colargmax_kernel, dim3((N + 31) / 32, B), dim3(256), 0, st, scores, M, N, i1);
+  const int mn = M > N ? M : N;
+  hipLaunchKernelGGL(mutual_kernel, dim3((mn + 255) / 256, B), dim3(256), 0, st, max0, i0, i1, M, N, threshold,
+                     (long long*)m0, (long long*)m1, ms0, ms1);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

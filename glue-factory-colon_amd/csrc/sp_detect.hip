@@ -1,0 +1,475 @@
+// SuperPoint detection tail: heat-map decode, NMS, key-point selection, descriptor sampling.
+// All HBM-bound byte/compare work: coalesced loads into LDS, wavefront reductions, no GEMM shapes.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------
+// softmax over 65 logits per 8x8 cell, drop the dustbin, depth-to-space:
+//   S[b, 8y+i, 8x+j] = P[b, 8i+j, y, x]      (superpoint_open.py:139-144; superpoint.py:231-235)
+// logits: [B*h*w][ld] (NHWC GEMM output, 65 valid columns).  One workgroup per cell row.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restrict__ logits, int ld, int h, int w,
+                                                          float* __restrict__ heat) {
+  extern __shared__ float sm[];  // [w][65] logits, then [w] max, [w] sum
+  float* lg = sm;
+  float* mx = sm + w * 65;
+  float* sinv = mx + w;
+  const int y = blockIdx.x % h, b = blockIdx.x / h;
+  const float* src = logits + ((size_t)b * h + y) * w * ld;
+  for (int i = threadIdx.x; i < w * 65; i += 256) {
+    int x = i / 65, c = i - x * 65;
+    lg[i] = src[(size_t)x * ld + c];
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < w; x += 256) {
+    float m = -INFINITY;
+    for (int c = 0; c < 65; ++c) m = fmaxf(m, lg[x * 65 + c]);
+    float s = 0.f;
+    for (int c = 0; c < 65; ++c) s += expf(lg[x * 65 + c] - m);
+    mx[x] = m;
+    sinv[x] = s;
+  }
+  __syncthreads();
+  const int W8 = w * 8;
+  float* dst = heat + ((size_t)b * h * 8 + y * 8) * W8;
+  for (int i = threadIdx.x; i < 8 * W8; i += 256) {
+    int row = i / W8, col = i - row * W8;
+    int x = col >> 3, j = col & 7;
+    dst[(size_t)row * W8 + col] = expf(lg[x * 65 + row * 8 + j] - mx[x]) / sinv[x];
+  }
+}
+
+int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* heat, hipStream_t st) {
+  size_t lds = (size_t)(w * 65 + 2 * w) * sizeof(float);
+  if (lds > 160 * 1024) return GFC_ERR_UNSUPPORTED;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(B * h), dim3(256), lds, st, logits, ld, h, w, heat);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// NMS (superpoint_open.py:36-51 == superpoint.py:63-83) fused with the border kill
+// (superpoint_open.py:148-154; superpoint.py:249-260).
+//   keep  = s == mp(s)
+//   twice: near = mp(keep) > 0;  t = near ? 0 : s;  keep |= (t == mp(t)) & ~near
+//   out   = keep ? s : 0
+// mp = (2r+1)^2 max-pool, stride 1, -inf padding.  The 5 dependent pools need a 5r halo, so a
+// 32x32 output tile works on a (32+10r)^2 LDS image; every pool is separable (row max, col max).
+// Float equality is evaluated on the same fp32 values the reference compares: bit-exact.
+// ------------------------------------------------------------------------------------------
+#define NT 32
+#define NR_MAX 4
+#define NRG (NT + 10 * NR_MAX)  // 72
+
+__device__ __forceinline__ void pool_rows(const float* src, float* dst, int R, int r, int tid) {
+  // horizontal running max: dst[y][x] = max_{|d|<=r} src[y][x+d]   (out of tile -> -inf)
+  for (int i = tid; i < R * R; i += 256) {
+    int y = i / R, x = i - y * R;
+    float m = -INFINITY;
+    int lo = max(x - r, 0), hi = min(x + r, R - 1);
+    for (int xx = lo; xx <= hi; ++xx) m = fmaxf(m, src[y * R + xx]);
+    dst[i] = m;
+  }
+}
+__device__ __forceinline__ void pool_cols(const float* src, float* dst, int R, int r, int tid) {
+  for (int i = tid; i < R * R; i += 256) {
+    int y = i / R, x = i - y * R;
+    float m = -INFINITY;
+    int lo = max(y - r, 0), hi = min(y + r, R - 1);
+    for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, src[yy * R + x]);
+    dst[i] = m;
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat, int H, int W, int r, int border,
+                                                  const int* __restrict__ valid_wh, float* __restrict__ out) {
+  __shared__ float s[NRG * NRG];   // scores (-inf outside the image)
+  __shared__ float t0[NRG * NRG];  // scratch
+  __shared__ float t1[NRG * NRG];  // scratch
+  __shared__ unsigned char keep[NRG * NRG];
+  const int tid = threadIdx.x;
+  const int tiles_x = (W + NT - 1) / NT;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  const int halo = 5 * r, R = NT + 2 * halo;
+  const int gx0 = tx * NT - halo, gy0 = ty * NT - halo;
+  const float* hb = heat + (size_t)b * H * W;
+  for (int i = tid; i < R * R; i += 256) {
+    int y = i / R, x = i - y * R;
+    int gy = gy0 + y, gx = gx0 + x;
+    s[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hb[(size_t)gy * W + gx] : -INFINITY;
+  }
+  __syncthreads();
+  if (r > 0) {
+    // keep = s == mp(s)
+    pool_rows(s, t0, R, r, tid);
+    __syncthreads();
+    pool_cols(t0, t1, R, r, tid);
+    __syncthreads();
+    for (int i = tid; i < R * R; i += 256) keep[i] = (s[i] == t1[i]) ? 1 : 0;
+    __syncthreads();
+    for (int it = 0; it < 2; ++it) {
+      // near = mp(keep) > 0  (t0 <- keep as float with -inf outside the image, pooled into t1)
+      for (int i = tid; i < R * R; i += 256) t1[i] = (s[i] == -INFINITY) ? -INFINITY : (float)keep[i];
+      __syncthreads();
+      pool_rows(t1, t0, R, r, tid);
+      __syncthreads();
+      pool_cols(t0, t1, R, r, tid);
+      __syncthreads();
+      // t0 <- near ? 0 : s  ; remember near in the high bit of keep
+      for (int i = tid; i < R * R; i += 256) {
+        bool near = t1[i] > 0.f;
+        keep[i] = (keep[i] & 1) | (near ? 2 : 0);
+        t0[i] = (s[i] == -INFINITY) ? -INFINITY : (near ? 0.f : s[i]);
+      }
+      __syncthreads();
+      pool_rows(t0, t1, R, r, tid);
+      __syncthreads();
+      // column pool of t1 compared against t0 in place: keep |= (t0 == mp(t0)) & ~near
+      for (int i = tid; i < R * R; i += 256) {
+        int y = i / R, x = i - y * R;
+        float m = -INFINITY;
+        int lo = max(y - r, 0), hi = min(y + r, R - 1);
+        for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, t1[yy * R + x]);
+        unsigned char k = keep[i];
+        if (!(k & 2) && t0[i] == m) k |= 1;
+        keep[i] = k & 1;
+      }
+      __syncthreads();
+    }
+  }
+  int vw = W, vh = H;
+  if (valid_wh) { vw = valid_wh[2 * b]; vh = valid_wh[2 * b + 1]; }
+  float* ob = out + (size_t)b * H * W;
+  for (int i = tid; i < NT * NT; i += 256) {
+    int y = i / NT, x = i - y * NT;
+    int gy = ty * NT + y, gx = tx * NT + x;
+    if (gy >= H || gx >= W) continue;
+    int li = (y + halo) * R + (x + halo);
+    float v = (r > 0) ? (keep[li] ? s[li] : 0.f) : s[li];
+    if (border > 0 && (gy < border || gx < border || gy >= vh - border || gx >= vw - border)) v = -1.f;
+    ob[(size_t)gy * W + gx] = v;
+  }
+}
+
+extern "C" int gfc_sp_nms(const float* heatmap, int B, int H, int W, int radius, int border,
+                          const int32_t* valid_wh, float* out, void* stream) {
+  if (!heatmap || !out || B <= 0 || H <= 0 || W <= 0 || radius < 0 || border < 0) return GFC_ERR_INVALID;
+  if (radius > NR_MAX) return GFC_ERR_UNSUPPORTED;
+  dim3 grid(((W + NT - 1) / NT) * ((H + NT - 1) / NT), B);
+  hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, (hipStream_t)stream, heatmap, H, W, radius, border, valid_wh, out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Selection (superpoint_open.py:156-192,54-58; superpoint.py:262-300,86-90): one workgroup
+// (1024 threads) per image.
+//   pass A  ordered compaction of the pixels with score > th (row-major) into 64-bit keys
+//           key = score_bits << 32 | (0xFFFFFFFF - linear_index)   (scores > th >= ... may be any
+//           float; order-preserving transform below) -- keys are unique, so the top-k set and its
+//           order (score descending, lower index first on ties) are fully determined;
+//   N <= k  emit the candidates as they are (row-major, unsorted -- the reference returns them so);
+//   N >  k  radix-select the k-th largest key (8 passes of 8 bits over the candidate list), gather
+//           the k winners into LDS, bitonic-sort them descending.
+// ------------------------------------------------------------------------------------------
+#define SEL_THREADS 1024
+#define SEL_MAXK 8192
+
+__device__ __forceinline__ unsigned int float_order_bits(float f) {
+  unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_from_order_bits(unsigned int o) {
+  unsigned int u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+  return __uint_as_float(u);
+}
+
+__device__ __forceinline__ unsigned int block_exclusive_scan(unsigned int v, unsigned int* total, unsigned int* wsum) {
+  // 1024 threads = 16 waves; returns exclusive prefix of v, *total = block sum
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned int inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned int n = __shfl_up(inc, o);
+    if (lane >= o) inc += n;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  unsigned int base = 0, tot = 0;
+  for (int i = 0; i < SEL_THREADS / 64; ++i) {
+    unsigned int w = wsum[i];
+    if (i < wave) base += w;
+    tot += w;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __restrict__ scores, int H, int W, float th,
+                                                             int k, int cap, float* __restrict__ kpts,
+                                                             float* __restrict__ kscores, int* __restrict__ counts,
+                                                             unsigned long long* __restrict__ cand_all) {
+  __shared__ unsigned long long keys[SEL_MAXK];
+  __shared__ unsigned int hist[256];
+  __shared__ unsigned int wsum[SEL_THREADS / 64];
+  __shared__ unsigned int sh_cnt;
+  __shared__ unsigned long long sh_prefix;
+  __shared__ unsigned int sh_remaining;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const long long HW = (long long)H * W;
+  const float* sb = scores + (size_t)b * HW;
+  unsigned long long* cand = cand_all + (size_t)b * HW;
+
+  // ---- pass A: ordered compaction ----
+  unsigned int n = 0;
+  for (long long base = 0; base < HW; base += SEL_THREADS * 4) {
+    long long i0 = base + (long long)tid * 4;
+    float v[4];
+    unsigned int flags = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      long long i = i0 + j;
+      v[j] = (i < HW) ? sb[i] : -INFINITY;
+      if (i < HW && v[j] > th) flags |= 1u << j;
+    }
+    unsigned int cnt = __popc(flags), tot;
+    unsigned int off = n + block_exclusive_scan(cnt, &tot, wsum);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (flags & (1u << j)) {
+        unsigned int idx = (unsigned int)(i0 + j);
+        cand[off++] = ((unsigned long long)float_order_bits(v[j]) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+      }
+    n += tot;
+  }
+  __syncthreads();
+
+  float* kp = kpts + (size_t)b * cap * 2;
+  float* ks = kscores + (size_t)b * cap;
+  if (k < 0 || n <= (unsigned int)k) {
+    // all candidates, row-major (unsorted)
+    unsigned int cnt = min(n, (unsigned int)cap);
+    for (unsigned int i = tid; i < cnt; i += SEL_THREADS) {
+      unsigned long long key = cand[i];
+      unsigned int idx = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+      kp[2 * i] = (float)(idx % W);
+      kp[2 * i + 1] = (float)(idx / W);
+      ks[i] = float_from_order_bits((unsigned int)(key >> 32));
+    }
+    for (unsigned int i = cnt + tid; i < (unsigned int)cap; i += SEL_THREADS) {
+      kp[2 * i] = 0.f; kp[2 * i + 1] = 0.f; ks[i] = 0.f;
+    }
+    if (tid == 0) counts[b] = (int)cnt;
+    return;
+  }
+
+  // ---- radix select: find the k-th largest key ----
+  if (tid == 0) { sh_prefix = 0ull; sh_remaining = (unsigned int)k; }
+  __syncthreads();
+  for (int pass = 7; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const unsigned long long prefix = sh_prefix;
+    const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
+    for (unsigned int i = tid; i < n; i += SEL_THREADS) {
+      unsigned long long key = cand[i];
+      if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 0xFF], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned int rem = sh_remaining, acc = 0;
+      int d = 255;
+      for (; d > 0; --d) {
+        if (acc + hist[d] >= rem) break;
+        acc += hist[d];
+      }
+      sh_prefix = prefix | ((unsigned long long)d << shift);
+      sh_remaining = rem - acc;
+    }
+    __syncthreads();
+  }
+  const unsigned long long kth = sh_prefix;  // exactly k keys are >= kth (keys are unique)
+  if (tid == 0) sh_cnt = 0;
+  __syncthreads();
+  for (unsigned int i = tid; i < n; i += SEL_THREADS) {
+    unsigned long long key = cand[i];
+    if (key >= kth) {
+      unsigned int slot = atomicAdd(&sh_cnt, 1u);
+      if (slot < SEL_MAXK) keys[slot] = key;
+    }
+  }
+  // pad to a power of two with zeros (smaller than any real key) and bitonic sort descending
+  unsigned int P = 1;
+  while (P < (unsigned int)k) P <<= 1;
+  __syncthreads();
+  for (unsigned int i = (unsigned int)k + tid; i < P; i += SEL_THREADS) keys[i] = 0ull;
+  __syncthreads();
+  for (unsigned int sz = 2; sz <= P; sz <<= 1) {
+    for (unsigned int st = sz >> 1; st > 0; st >>= 1) {
+      for (unsigned int i = tid; i < P / 2; i += SEL_THREADS) {
+        unsigned int lo = (i / st) * (st * 2) + (i % st);
+        unsigned int hi = lo + st;
+        bool desc = ((lo & sz) == 0);
+        unsigned long long a = keys[lo], c = keys[hi];
+        if ((a < c) == desc) { keys[lo] = c; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (unsigned int i = tid; i < (unsigned int)k; i += SEL_THREADS) {
+    unsigned long long key = keys[i];
+    unsigned int idx = 0xFFFFFFFFu - (unsigned int)(key & 0xFFFFFFFFull);
+    kp[2 * i] = (float)(idx % W);
+    kp[2 * i + 1] = (float)(idx / W);
+    ks[i] = float_from_order_bits((unsigned int)(key >> 32));
+  }
+  for (unsigned int i = (unsigned int)k + tid; i < (unsigned int)cap; i += SEL_THREADS) {
+    kp[2 * i] = 0.f; kp[2 * i + 1] = 0.f; ks[i] = 0.f;
+  }
+  if (tid == 0) counts[b] = k;
+}
+
+extern "C" size_t gfc_sp_select_workspace_bytes(int B, int H, int W) {
+  return gfc_align((size_t)B * H * W * sizeof(unsigned long long));
+}
+
+extern "C" int gfc_sp_select(const float* scores, int B, int H, int W, float threshold, int k, int cap, float* kpts,
+                             float* kscores, int32_t* counts, void* ws, size_t ws_bytes, void* stream) {
+  if (!scores || !kpts || !kscores || !counts || !ws || B <= 0 || H <= 0 || W <= 0 || cap <= 0) return GFC_ERR_INVALID;
+  if (k >= 0 && cap < k) return GFC_ERR_INVALID;
+  if (k < 0 && (long long)cap < (long long)H * W) return GFC_ERR_INVALID;
+  if (k > SEL_MAXK) return GFC_ERR_UNSUPPORTED;
+  if (ws_bytes < gfc_sp_select_workspace_bytes(B, H, W)) return GFC_ERR_WORKSPACE;
+  if (k == 0) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(select_kernel, dim3(B), dim3(SEL_THREADS), 0, (hipStream_t)stream, scores, H, W, threshold, k, cap,
+                     kpts, kscores, counts, reinterpret_cast<unsigned long long*>(ws));
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Descriptor sampling: grid_sample(bilinear, zeros padding) of the L2-normalised dense map at the
+// key points, then L2 normalisation (superpoint_open.py:22-33; superpoint.py:120-152).
+// One wave per key point, 4 channels per lane (D = 256).  The dense map is stored un-normalised;
+// each corner is normalised on the fly (x / max(||x||, 1e-12), F.normalize), which removes a
+// full pass over the map.
+// ------------------------------------------------------------------------------------------
+template <int VPL>  // float4 per lane: D = 256 * VPL
+__global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ dense, int B, int h, int w,
+                                                     const float* __restrict__ kpts, const int* __restrict__ n_kpts,
+                                                     int cap, int mode, float* __restrict__ out,
+                                                     float* __restrict__ kpts_out) {
+  const int D = 256 * VPL;
+  const int lane = threadIdx.x & 63;
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (long long)B * cap) return;
+  const int b = (int)(wid / cap), i = (int)(wid % cap);
+  const int n = n_kpts ? n_kpts[b] : cap;
+  float* o = out + (size_t)wid * D;
+  const float kx = kpts[2 * wid], ky = kpts[2 * wid + 1];
+  if (i >= n) {
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) *reinterpret_cast<float4*>(o + (v * 64 + lane) * 4) = make_float4(0, 0, 0, 0);
+    return;
+  }
+  // normalised grid coordinate, op by op as the reference computes it in fp32
+  float gx, gy, ix, iy;
+  const float s = 8.f;
+  if (mode == GFC_SAMPLE_OPEN) {
+    gx = (kx + 0.5f) / ((float)w * s);
+    gy = (ky + 0.5f) / ((float)h * s);
+  } else if (mode == GFC_SAMPLE_LEGACY) {
+    gx = ((kx - 4.f) + 0.5f) / (float)((double)w * 8.0 - 4.0 - 0.5);
+    gy = ((ky - 4.f) + 0.5f) / (float)((double)h * 8.0 - 4.0 - 0.5);
+  } else {
+    gx = kx / ((float)w * s);
+    gy = ky / ((float)h * s);
+  }
+  gx = gx * 2.f - 1.f;
+  gy = gy * 2.f - 1.f;
+  if (mode == GFC_SAMPLE_LEGACY) {  // align_corners=True
+    ix = ((gx + 1.f) / 2.f) * (float)(w - 1);
+    iy = ((gy + 1.f) / 2.f) * (float)(h - 1);
+  } else {
+    ix = ((gx + 1.f) * (float)w - 1.f) / 2.f;
+    iy = ((gy + 1.f) * (float)h - 1.f) / 2.f;
+  }
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float wx1 = ix - fx, wy1 = iy - fy, wx0 = (fx + 1.f) - ix, wy0 = (fy + 1.f) - iy;
+  const float cw[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};  // nw, ne, sw, se
+  float4 acc[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0, 0, 0, 0);
+  const float* db = dense + (size_t)b * h * w * D;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
+    if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;  // zeros padding (wave-uniform)
+    const float* p = db + ((size_t)yy * w + xx) * D;
+    float4 val[VPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      val[v] = *reinterpret_cast<const float4*>(p + (v * 64 + lane) * 4);
+      ss += val[v].x * val[v].x + val[v].y * val[v].y + val[v].z * val[v].z + val[v].w * val[v].w;
+    }
+    ss = wave_sum(ss);
+    const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      acc[v].x += (val[v].x / den) * cw[c];
+      acc[v].y += (val[v].y / den) * cw[c];
+      acc[v].z += (val[v].z / den) * cw[c];
+      acc[v].w += (val[v].w / den) * cw[c];
+    }
+  }
+  float ss = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) ss += acc[v].x * acc[v].x + acc[v].y * acc[v].y + acc[v].z * acc[v].z + acc[v].w * acc[v].w;
+  ss = wave_sum(ss);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+  for (int v = 0; v < VPL; ++v)
+    *reinterpret_cast<float4*>(o + (v * 64 + lane) * 4) =
+        make_float4(acc[v].x / den, acc[v].y / den, acc[v].z / den, acc[v].w / den);
+  if (kpts_out && lane == 0) {
+    kpts_out[2 * wid] = kx + 0.5f;
+    kpts_out[2 * wid + 1] = ky + 0.5f;
+  }
+}
+
+extern "C" int gfc_sp_sample(const float* desc_raw, int B, int h, int w, int D, const float* kpts,
+                             const int32_t* n_kpts, int cap, int mode, float* out, float* kpts_out, void* stream) {
+  if (!desc_raw || !kpts || !out || B <= 0 || h <= 0 || w <= 0 || cap <= 0) return GFC_ERR_INVALID;
+  if (mode < 0 || mode > 2) return GFC_ERR_INVALID;
+  if (D != 256) return GFC_ERR_UNSUPPORTED;
+  long long waves = (long long)B * cap;
+  hipLaunchKernelGGL(sample_kernel<1>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, desc_raw, B,
+                     h, w, kpts, n_kpts, cap, mode, out, kpts_out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, long long rows, int width) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float* p = x + (size_t)row * width;
+  float ss = 0.f;
+  for (int c = lane; c < width; c += 64) ss += p[c] * p[c];
+  ss = wave_sum(ss);
+  const float den = fmaxf(sqrtf(ss), 1e-12f);
+  for (int c = lane; c < width; c += 64) p[c] = p[c] / den;
+}
+
+extern "C" int gfc_l2norm_rows(float* x, long long rows, int width, void* stream) {
+  if (!x || rows <= 0 || width <= 0) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows,
+                     width);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

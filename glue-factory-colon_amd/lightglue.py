@@ -1,0 +1,252 @@
+"""LightGlue matcher on MI355X -- drop-in for `gluefactory.models.matchers.lightglue`
+(reference file gluefactory/models/matchers/lightglue.py:322-640, inference path).
+
+Same configuration keys, same `forward(data) -> dict` contract (lightglue.py:422-553) and
+the same state-dict key names (lightglue.py:349-408), including the legacy
+`self_attn.{i}` -> `transformers.{i}.self_attn` rename (lightglue.py:394-401), so the official
+`superpoint_lightglue.pth` / `disk_lightglue.pth` load unchanged.  Like the reference class it
+is a plain nn.Module (not a BaseModel) resolved through `__main_model__`.  The torch
+sub-modules are parameter containers only; the forward pass is one call into libgfc_amd.so.
+
+    model.matcher.name = glue_factory_colon_amd.lightglue
+"""
+import ctypes
+from pathlib import Path
+
+import torch
+from torch import nn
+
+from . import _native as nat
+from . import weights as _weights
+from .base_model import Conf, conf_get, merge
+
+
+def _ffn(d):
+    return nn.Sequential(nn.Linear(2 * d, 2 * d), nn.LayerNorm(2 * d, elementwise_affine=True), nn.GELU(),
+                         nn.Linear(2 * d, d))
+
+
+class _SelfBlock(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.Wqkv = nn.Linear(d, 3 * d)
+        self.out_proj = nn.Linear(d, d)
+        self.ffn = _ffn(d)
+
+
+class _CrossBlock(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.to_qk = nn.Linear(d, d)
+        self.to_v = nn.Linear(d, d)
+        self.to_out = nn.Linear(d, d)
+        self.ffn = _ffn(d)
+
+
+class _Layer(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.self_attn = _SelfBlock(d)
+        self.cross_attn = _CrossBlock(d)
+
+
+class _PosEnc(nn.Module):
+    def __init__(self, m, f_dim):
+        super().__init__()
+        self.Wr = nn.Linear(m, f_dim // 2, bias=False)
+
+
+class _Assignment(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.matchability = nn.Linear(d, 1)
+        self.final_proj = nn.Linear(d, d)
+
+
+class _TokenConfidence(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.token = nn.Sequential(nn.Linear(d, 1), nn.Sigmoid())
+
+
+class LightGlue(nn.Module):
+    default_conf = {
+        "name": "lightglue",
+        "input_dim": 256,
+        "add_scale_ori": False,
+        "descriptor_dim": 256,
+        "n_layers": 9,
+        "num_heads": 4,
+        "flash": False,
+        "mp": False,
+        "depth_confidence": -1,
+        "width_confidence": -1,
+        "filter_threshold": 0.0,
+        "checkpointed": False,
+        "weights": None,  # path of a checkpoint, or "synthetic[:seed]" for the name-seeded weights
+        "weights_from_version": "v0.1_arxiv",
+        "loss": {"gamma": 1.0, "fn": "nll", "nll_balancing": 0.5},
+    }
+    required_data_keys = ["keypoints0", "keypoints1", "descriptors0", "descriptors1"]
+
+    def __init__(self, conf) -> None:
+        super().__init__()
+        self.conf = conf = Conf(merge(self.default_conf, conf))
+        if conf.descriptor_dim != 256 or conf.num_heads != 4:
+            raise NotImplementedError("the MI355X kernels are built for descriptor_dim 256, 4 heads (head_dim 64)")
+        if conf.add_scale_ori:
+            raise NotImplementedError("add_scale_ori (SIFT-style scale/orientation inputs) is not built")
+        if conf.n_layers > nat.GFC_LG_MAX_LAYERS:
+            raise NotImplementedError(f"at most {nat.GFC_LG_MAX_LAYERS} layers")
+        if conf.input_dim != conf.descriptor_dim:
+            if conf.input_dim % 32:
+                raise NotImplementedError("input_dim must be a multiple of 32")
+            self.input_proj = nn.Linear(conf.input_dim, conf.descriptor_dim, bias=True)
+        else:
+            self.input_proj = nn.Identity()
+        d, n = conf.descriptor_dim, conf.n_layers
+        head_dim = d // conf.num_heads
+        self.posenc = _PosEnc(2, head_dim)
+        self.transformers = nn.ModuleList([_Layer(d) for _ in range(n)])
+        self.log_assignment = nn.ModuleList([_Assignment(d) for _ in range(n)])
+        self.token_confidence = nn.ModuleList([_TokenConfidence(d) for _ in range(n - 1)])
+        self.register_buffer("confidence_thresholds", _weights.confidence_thresholds(n))
+        self._packed = None
+        self._ws = nat.Workspace()
+        self.are_weights_initialized = False
+
+        w = conf.weights
+        if w is not None:
+            if Path(str(w)).exists():
+                self.load_state_dict(torch.load(str(w), map_location="cpu"), strict=False)
+            elif isinstance(w, str) and w.startswith("synthetic"):
+                seed = int(w.split(":")[1]) if ":" in w else 0
+                self.load_state_dict(_weights.lightglue_state_dict(seed, input_dim=conf.input_dim, n_layers=n),
+                                     strict=False)
+            else:
+                # the reference downloads `{weights}_lightglue.pth` here (lightglue.py:385-392); no network
+                raise FileNotFoundError(f"weights {w!r} not found (no download is attempted)")
+
+    # -- weights ------------------------------------------------------------------------
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        for i in range(self.conf.n_layers):  # legacy key names, lightglue.py:394-401
+            state_dict = {k.replace(f"self_attn.{i}", f"transformers.{i}.self_attn"): v for k, v in state_dict.items()}
+            state_dict = {k.replace(f"cross_attn.{i}", f"transformers.{i}.cross_attn"): v
+                          for k, v in state_dict.items()}
+        ret = super().load_state_dict(state_dict, *args, **kwargs)
+        self._packed = None
+        self.are_weights_initialized = True
+        return ret
+
+    def _apply(self, fn, *args, **kwargs):
+        self._packed = None
+        return super()._apply(fn, *args, **kwargs)
+
+    def is_initialized(self):
+        return self.are_weights_initialized
+
+    def _pack(self, device):
+        conf = self.conf
+        keep = []
+
+        def dev(t):
+            t = t.detach().to(device=device, dtype=torch.float32).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        p = nat.LgParams()
+        p.n_layers, p.input_dim = conf.n_layers, conf.input_dim
+        if conf.input_dim != conf.descriptor_dim:
+            p.input_proj_w, p.input_proj_b = dev(self.input_proj.weight), dev(self.input_proj.bias)
+        p.posenc_wr = dev(self.posenc.Wr.weight)
+        d, h = conf.descriptor_dim, conf.num_heads
+        dh = d // h
+        # Wqkv rows: state-dict row = head*(3*dh) + dd*3 + s  ->  packed row = s*d + head*dh + dd
+        idx = torch.arange(3 * d)
+        s_, rem = idx // d, idx % d
+        head, dd = rem // dh, rem % dh
+        src = head * (3 * dh) + dd * 3 + s_
+        for i, layer in enumerate(self.transformers):
+            sa, ca = layer.self_attn, layer.cross_attn
+            p.wqkv[i] = dev(sa.Wqkv.weight[src])
+            p.bqkv[i] = dev(sa.Wqkv.bias[src])
+            p.s_out_w[i], p.s_out_b[i] = dev(sa.out_proj.weight), dev(sa.out_proj.bias)
+            p.s_ffn0_w[i], p.s_ffn0_b[i] = dev(sa.ffn[0].weight), dev(sa.ffn[0].bias)
+            p.s_ln_g[i], p.s_ln_b[i] = dev(sa.ffn[1].weight), dev(sa.ffn[1].bias)
+            p.s_ffn3_w[i], p.s_ffn3_b[i] = dev(sa.ffn[3].weight), dev(sa.ffn[3].bias)
+            p.c_qkv_w[i] = dev(torch.cat([ca.to_qk.weight, ca.to_v.weight], 0))
+            p.c_qkv_b[i] = dev(torch.cat([ca.to_qk.bias, ca.to_v.bias], 0))
+            p.c_out_w[i], p.c_out_b[i] = dev(ca.to_out.weight), dev(ca.to_out.bias)
+            p.c_ffn0_w[i], p.c_ffn0_b[i] = dev(ca.ffn[0].weight), dev(ca.ffn[0].bias)
+            p.c_ln_g[i], p.c_ln_b[i] = dev(ca.ffn[1].weight), dev(ca.ffn[1].bias)
+            p.c_ffn3_w[i], p.c_ffn3_b[i] = dev(ca.ffn[3].weight), dev(ca.ffn[3].bias)
+        last = self.log_assignment[conf.n_layers - 1]
+        p.final_proj_w, p.final_proj_b = dev(last.final_proj.weight), dev(last.final_proj.bias)
+        p.matchability_w, p.matchability_b = dev(last.matchability.weight.reshape(-1)), dev(last.matchability.bias)
+        return p, keep, device
+
+    # -- forward ------------------------------------------------------------------------
+    def forward(self, data: dict) -> dict:
+        for key in self.required_data_keys:
+            assert key in data, f"Missing key {key} in data"
+        conf = self.conf
+        if self.training:
+            raise NotImplementedError("training (loss, checkpointing) is out of scope: inference path only")
+        if conf.depth_confidence > 0 or conf.width_confidence > 0:
+            raise NotImplementedError("adaptive depth / width (early stop, point pruning) is not built; "
+                                      "set depth_confidence = width_confidence = -1")
+        if not self.are_weights_initialized:
+            raise RuntimeError("LightGlue weights are not loaded (conf.weights or load_state_dict)")
+        kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
+        nat.require_cuda(kpts0, "data['keypoints0']")
+        b, m, _ = kpts0.shape
+        b, n, _ = kpts1.shape
+        device = kpts0.device
+        # like the reference (lightglue.py:430-434) the image sizes come from the views
+        size0 = data["view0"].get("image_size")
+        size1 = data["view1"].get("image_size")
+        if size0 is None or size1 is None:
+            raise NotImplementedError("view0/view1 must carry image_size")
+        desc0 = data["descriptors0"].contiguous().float()
+        desc1 = data["descriptors1"].contiguous().float()
+        assert desc0.shape[-1] == conf.input_dim
+        assert desc1.shape[-1] == conf.input_dim
+        m0 = torch.full((b, m), -1, device=device, dtype=torch.long)
+        m1 = torch.full((b, n), -1, device=device, dtype=torch.long)
+        ms0 = torch.zeros((b, m), device=device)
+        ms1 = torch.zeros((b, n), device=device)
+        scores = torch.zeros((b, m + 1, n + 1), device=device)
+        ref0 = torch.zeros((b, 1, m, conf.descriptor_dim), device=device)
+        ref1 = torch.zeros((b, 1, n, conf.descriptor_dim), device=device)
+        if m > 0 and n > 0:
+            if self._packed is None or self._packed[2] != device:
+                self._packed = self._pack(device)
+            lib = nat.lib()
+            ws = self._ws.get(lib.gfc_lg_workspace_bytes(b, m, n), device)
+            s0 = torch.as_tensor(size0, device=device, dtype=torch.float32).expand(b, 2).contiguous()
+            s1 = torch.as_tensor(size1, device=device, dtype=torch.float32).expand(b, 2).contiguous()
+            k0 = kpts0.contiguous().float()
+            k1 = kpts1.contiguous().float()
+            nat.check(lib.gfc_lg_forward(
+                ctypes.byref(self._packed[0]), nat.ptr(k0), nat.ptr(k1), nat.ptr(desc0), nat.ptr(desc1), nat.ptr(s0),
+                nat.ptr(s1), b, m, n, float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0),
+                nat.ptr(ms1), nat.ptr(scores), nat.ptr(ref0), nat.ptr(ref1), nat.ptr(ws), ws.numel(),
+                nat.stream_ptr(device)), "gfc_lg_forward")
+        # m == 0 or n == 0: the reference's early return (lightglue.py:298-303) -> all -1 / zeros
+        return {
+            "matches0": m0,
+            "matches1": m1,
+            "matching_scores0": ms0,
+            "matching_scores1": ms1,
+            "ref_descriptors0": ref0,
+            "ref_descriptors1": ref1,
+            "log_assignment": scores,
+            "prune0": torch.ones_like(ms0) * conf.n_layers,
+            "prune1": torch.ones_like(ms1) * conf.n_layers,
+        }
+
+    def loss(self, pred, data):
+        raise NotImplementedError("training loss (lightglue.py:588-637) is out of scope")
+
+
+__main_model__ = LightGlue

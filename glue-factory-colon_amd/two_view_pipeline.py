@@ -1,0 +1,118 @@
+"""Two-view pipeline: extractor on both views, key suffixing, matcher, timing keys.
+
+Counterpart of gluefactory/models/two_view_pipeline.py:278-405 (`TwoViewPipeline._forward`)
+for the components that are in scope (extractor + matcher; filter / solver / ground truth /
+key-point rotation augmentation are outside the hot path and rejected).  The real
+`gluefactory.models.two_view_pipeline.TwoViewPipeline` works unchanged with this package's
+modules selected by name; this look-alike exists because the reference does not travel to the
+GPU box.  Convention (two_view_pipeline.py:9-10): m0[i] = index in image 1 matched to keypoint
+i of image 0, -1 if unmatched.
+"""
+import time
+
+import torch
+
+from .base_model import BaseModel, conf_get, to_plain
+from .registry import get_model
+
+
+class TwoViewPipeline(BaseModel):
+    default_conf = {
+        "extractor": {"name": None, "trainable": False},
+        "matcher": {"name": None},
+        "filter": {"name": None},
+        "solver": {"name": None},
+        "ground_truth": {"name": None},
+        "allow_no_extract": False,
+        "run_gt_in_forward": False,
+    }
+    required_data_keys = ["view0", "view1"]
+    strict_conf = False
+    components = ["extractor", "matcher", "filter", "solver", "ground_truth"]
+
+    def _init(self, conf):
+        for comp in ("filter", "solver", "ground_truth"):
+            if conf_get(conf_get(conf, comp, {}), "name"):
+                raise NotImplementedError(f"pipeline component {comp!r} is outside the accelerated hot path")
+        ext = conf_get(conf, "extractor")
+        if conf_get(ext, "name"):
+            self.extractor = get_model(conf_get(ext, "name"))(to_plain(ext))
+        mat = conf_get(conf, "matcher")
+        if conf_get(mat, "name"):
+            self.matcher = get_model(conf_get(mat, "name"))(to_plain(mat))
+
+    def is_initialized(self):
+        ok = True
+        for name in ("extractor", "matcher"):
+            m = getattr(self, name, None)
+            if m is not None:
+                ok = ok and bool(m.is_initialized())
+        return ok
+
+    @staticmethod
+    def _timed(device, fn):
+        """two_view_pipeline.py:78-102: device-synchronised wall clock + peak-memory delta."""
+        mem = None
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+            baseline = torch.cuda.memory_allocated(device)
+            torch.cuda.reset_peak_memory_stats(device)
+        start = time.perf_counter()
+        out = fn()
+        if device.type == "cuda":
+            torch.cuda.synchronize(device)
+            mem = max(torch.cuda.max_memory_allocated(device) - baseline, 0) / (1024 ** 2)
+        return out, (time.perf_counter() - start) * 1e3, mem
+
+    def extract_view(self, data, i):
+        data_i = data[f"view{i}"]
+        pred_i = dict(data_i.get("cache", {}))
+        skip = len(pred_i) > 0 and conf_get(self.conf, "allow_no_extract")
+        t_ms = core_ms = mem = None
+        if hasattr(self, "extractor") and not skip:
+            inp = data_i if not pred_i else {**data_i, **pred_i}
+            out, t_ms, mem = self._timed(data_i["image"].device, lambda: self.extractor(inp))
+            core_ms = out.pop("extractor_core_time_ms", None)
+            pred_i = {**pred_i, **out}
+        return pred_i, t_ms, core_ms, mem
+
+    def _forward(self, data):
+        image0, image1 = data["view0"]["image"], data["view1"]["image"]
+        device, b = image0.device, image0.shape[0]
+
+        def full(v):
+            return torch.full((b,), float(v), device=device, dtype=torch.float32)
+
+        pred0, t0, c0, mem0 = self.extract_view(data, "0")
+        pred1, t1, c1, mem1 = self.extract_view(data, "1")
+        pred = {**{k + "0": v for k, v in pred0.items()}, **{k + "1": v for k, v in pred1.items()}}
+        t_match = mem_match = None
+        if hasattr(self, "matcher"):
+            out, t_match, mem_match = self._timed(device, lambda: self.matcher({**data, **pred}))
+            pred = {**pred, **out}
+        ext_times = [t for t in (t0, t1) if t is not None]
+        if ext_times:
+            pred["extractor_time_ms"] = full(sum(ext_times))
+            cores = [c for c in (c0, c1) if c is not None]
+            if cores:
+                pred["extractor_core_time_ms"] = sum(cores)
+            total = sum(ext_times)
+            if t_match is not None:
+                pred["matcher_time_ms"] = full(t_match)
+                total += t_match
+            pred["total_time_ms"] = full(total)
+        elif t_match is not None:
+            pred["total_time_ms"] = full(t_match)
+        ext_mem = [m for m in (mem0, mem1) if m is not None]
+        if ext_mem:
+            pred["extractor_memory_mb"] = full(sum(ext_mem))
+        if mem_match is not None:
+            pred["matcher_memory_mb"] = full(mem_match)
+        pred["pair_resolution"] = full(image0.shape[-2] * image0.shape[-1] + image1.shape[-2] * image1.shape[-1])
+        return pred
+
+    def loss(self, pred, data):
+        raise NotImplementedError("training is out of scope")
+
+
+__main_model__ = TwoViewPipeline

@@ -1,0 +1,233 @@
+/* gfc_amd.h -- C ABI of libgfc_amd.so: SuperPoint + LightGlue hot path on MI355X (gfx950).
+ *
+ * The reference (ipastore/glue-factory-colon) is pure Python on PyTorch: it has no FFI
+ * for this path.  The boundary it offers is the model registry
+ * (gluefactory/models/__init__.py:7-30 `get_model`) and the module contract
+ * `BaseModel.forward(data: dict) -> dict` (gluefactory/models/base_model.py:101-113).
+ * Each entry point below replaces the ATen op sequence of one reference function; the
+ * reference file:line it replaces is cited on every declaration.  The Python binding a
+ * maintainer adds is shown in INTEGRATION.md (ctypes, no torch types cross this line).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (hipMalloc'ed or torch-allocated) unless marked
+ *     "host"; fp32 everywhere, int32 for counts/tables, int64 for match indices
+ *     (the reference returns torch.long, lightglue.py:294-319);
+ *   - no allocation, no global state, no synchronisation inside: the caller passes a
+ *     workspace of at least gfc_*_workspace_bytes() and a hipStream_t (as void*);
+ *     every kernel is enqueued on that stream and the call returns immediately;
+ *   - return value: 0 = ok, otherwise a gfc_status.  Nothing is written on error.
+ *   - activations inside the extractor are NHWC ("channels last").
+ */
+#ifndef GFC_AMD_H
+#define GFC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  GFC_OK = 0,
+  GFC_ERR_INVALID = 1,     /* bad shape / null pointer / unsupported combination of arguments */
+  GFC_ERR_WORKSPACE = 2,   /* workspace smaller than gfc_*_workspace_bytes() */
+  GFC_ERR_UNSUPPORTED = 3, /* valid for the reference, not built here (e.g. nms_radius > 4) */
+  GFC_ERR_LAUNCH = 4       /* hipGetLastError() != hipSuccess after a launch */
+} gfc_status;
+
+/* Library / device identification ("gfx950" builds only). */
+const char* gfc_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Primitives (also exported so that parity tests can pin each kernel in isolation)
+ * ---------------------------------------------------------------------------------- */
+
+/* Re-pack a conv weight from the state-dict layout [Cout][Cin][3][3] to the kernel
+ * layout [tap=ky*3+kx][Cout][Cin].  (nn.Conv2d weights, superpoint_open.py:64-66) */
+int gfc_pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
+
+/* 3x3 convolution, stride 1, zero padding 1, NHWC, fused epilogue
+ *   y = conv(x) + bias;  if relu: y = max(y,0);  if scale: y = y*scale + shift;
+ *   if pool: 2x2/2 max-pool of y (floor semantics).
+ * Replaces VGGBlock (superpoint_open.py:61-77: conv -> ReLU -> BatchNorm(eval)) followed by
+ * nn.MaxPool2d(2,2) (superpoint_open.py:104-106), and conv+ReLU(+pool) of
+ * gluefactory_nonfree/superpoint.py:214-224.  cin % 32 == 0 (or cin == 1), cout % 64 == 0.
+ * x [B,H,W,cin], w packed [9][cout][cin] (cin == 1: [9][cout]), y [B,Ho,Wo,cout]. */
+int gfc_conv3x3(const float* x, const float* w_packed, const float* bias, const float* scale,
+                const float* shift, float* y, int B, int H, int W, int cin, int cout, int relu,
+                int pool, void* stream);
+
+/* y[M,N] = epilogue( [A0 | A1][M,K0+K1] * W[N,K0+K1]^T + bias ).  Row-major, leading
+ * dimensions in floats.  Replaces nn.Linear / 1x1 conv (F.linear -> addmm) at
+ * lightglue.py:139-148,158,163-164,181-189 and superpoint_open.py:112-118.
+ *   A1 may be NULL (K1 = 0): the two-source form implements torch.cat([x, msg], -1) of
+ *   lightglue.py:164,221-222 without materialising the concatenation.
+ *   scale/shift (per column, nullable): y = y*scale + shift  (BatchNorm of the 1x1 heads)
+ *   alpha: y *= alpha (final_proj / d^(1/4), lightglue.py:281-284)
+ *   residual (nullable, ld = ldy): y += residual (lightglue.py:164)
+ *   rot_cos/rot_sin (nullable, [M,64]): rotary embedding applied to columns < rot_cols,
+ *     pairing adjacent columns (lightglue.py:43-50,160-161); columns are head-major, 64 wide.
+ * K0, K1 multiples of 32. */
+int gfc_linear(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W,
+               int ldw, const float* bias, const float* scale, const float* shift, float alpha,
+               const float* residual, const float* rot_cos, const float* rot_sin, int rot_cols,
+               float* Y, int ldy, int M, int N, void* stream);
+
+/* Batched similarity: for z < batch: Y_z[M,N] = A_z[M,K] * B_z[N,K]^T (einsum "bmd,bnd->bmn",
+ * lightglue.py:285).  Strides between batch entries in floats. */
+int gfc_batched_nt(const float* A, int lda, long long strideA, const float* Bm, int ldb,
+                   long long strideB, float* Y, int ldy, long long strideY, int M, int N, int K,
+                   int batch, void* stream);
+
+/* Multi-head attention over packed rows, head_dim 64, fp32 MFMA, never materialising the
+ * score matrix.  problems[p] = {q_row0, n_q, kv_row0, n_kv} (int32 x4, device).  For every
+ * problem and head h:  O[q_row0+i, 64h:64h+64] = softmax_j(Q_i . K_j * scale) V_j.
+ * Replaces F.scaled_dot_product_attention (lightglue.py:119-122) and, called with the two
+ * directions as two problems, the bidirectional cross attention of lightglue.py:207-217. */
+int gfc_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                  int ldo, const int32_t* problems, int n_problems, int max_nq, int heads, float scale,
+                  void* stream);
+
+/* In-place LayerNorm(eps 1e-5, affine) + exact (erf) GELU over rows of width 512.
+ * Replaces ffn[1], ffn[2] (lightglue.py:143-148). */
+int gfc_layernorm_gelu(float* x, int ld, int rows, int width, const float* gamma, const float* beta,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * SuperPoint extractor
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  /* encoder conv1a..conv4b.  w[0]: [9][64] (cin = 1); w[1..7]: packed [9][cout][cin].
+   * scale/shift: folded eval-mode BatchNorm (alpha = gamma/sqrt(var+eps), beta - mean*alpha),
+   * NULL for the official (no-BN) variant. */
+  const float* w[8];
+  const float* bias[8];
+  const float* scale[8];
+  const float* shift[8];
+  /* both 3x3 heads merged: 128 -> 512 = [detector hidden | descriptor hidden] */
+  const float* wh;
+  const float* bias_h;
+  const float* scale_h;
+  const float* shift_h;
+  /* 1x1 detector 256 -> 65 ([65][256]) and 1x1 descriptor 256 -> desc_dim ([desc_dim][256]) */
+  const float* wp;
+  const float* bias_p;
+  const float* scale_p;
+  const float* shift_p;
+  const float* wd;
+  const float* bias_d;
+  const float* scale_d;
+  const float* shift_d;
+  int desc_dim;
+} gfc_sp_params;
+
+typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;
+
+size_t gfc_sp_workspace_bytes(int B, int C, int H, int W);
+
+/* image [B,C,H,W] (C = 1 or 3, RGB -> grey fused) -> heat-map [B, 8*(H/8), 8*(W/8)] (softmax over
+ * 65 logits, dustbin dropped, depth-to-space) and raw descriptor map [B,H/8,W/8,desc_dim]
+ * (NHWC, before L2 normalisation).  superpoint_open.py:128-144; superpoint.py:208-241. */
+int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, int C, int H, int W, float* heatmap,
+                 float* desc_raw, void* ws, size_t ws_bytes, void* stream);
+
+/* Max-pool NMS with two recovery rounds, then outer `border` rows/cols := -1.
+ * valid_wh (nullable, int32 [B,2] = (w,h)): right/bottom border measured from the true image
+ * extent.  superpoint_open.py:36-51,148-154; superpoint.py:63-83,249-260.  radius <= 4. */
+int gfc_sp_nms(const float* heatmap, int B, int H, int W, int radius, int border, const int32_t* valid_wh,
+               float* out, void* stream);
+
+size_t gfc_sp_select_workspace_bytes(int B, int H, int W);
+
+/* Per image: candidates = pixels with score > threshold in row-major order; if more than k
+ * (k < 0: unlimited) the k best by descending score (ties: lower linear index first), else all
+ * of them in row-major order.  kpts [B,cap,2] (x,y as floats), scores [B,cap], counts [B].
+ * cap = row capacity of the output arrays (>= k when k >= 0; H*W when unlimited).
+ * superpoint_open.py:156-192,54-58; superpoint.py:262-300,86-90. */
+int gfc_sp_select(const float* scores, int B, int H, int W, float threshold, int k, int cap, float* kpts,
+                  float* kscores, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+
+/* Bilinear sampling of L2-normalised dense descriptors at keypoints + L2 normalisation.
+ * desc_raw [B,h,w,D] un-normalised (normalisation over D is applied per corner on the fly),
+ * kpts [B,cap,2] integer-valued pixel coordinates, n_kpts [B] (nullable = cap for all),
+ * out [B,cap,D].  If kpts_out != NULL it receives kpts + 0.5 (may alias kpts).
+ * superpoint_open.py:22-33,133-135,221; superpoint.py:120-152. */
+int gfc_sp_sample(const float* desc_raw, int B, int h, int w, int D, const float* kpts, const int32_t* n_kpts,
+                  int cap, int mode, float* out, float* kpts_out, void* stream);
+
+/* L2-normalise rows in place (dense_outputs: F.normalize over channels, superpoint_open.py:133-135). */
+int gfc_l2norm_rows(float* x, long long rows, int width, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LightGlue matcher
+ * ---------------------------------------------------------------------------------- */
+#define GFC_LG_MAX_LAYERS 16
+typedef struct {
+  int n_layers;    /* 9 */
+  int input_dim;   /* 256, or 128 with input_proj */
+  const float* input_proj_w; /* [256][input_dim] or NULL */
+  const float* input_proj_b;
+  const float* posenc_wr;    /* [32][2] */
+  /* self block.  wqkv rows re-ordered to [q(256) | k(256) | v(256)], each head-major:
+   * new row s*256 + h*64 + d  <-  state-dict row h*192 + d*3 + s   (lightglue.py:157-159) */
+  const float* wqkv[GFC_LG_MAX_LAYERS];
+  const float* bqkv[GFC_LG_MAX_LAYERS];
+  const float* s_out_w[GFC_LG_MAX_LAYERS];
+  const float* s_out_b[GFC_LG_MAX_LAYERS];
+  const float* s_ffn0_w[GFC_LG_MAX_LAYERS]; /* [512][512] */
+  const float* s_ffn0_b[GFC_LG_MAX_LAYERS];
+  const float* s_ln_g[GFC_LG_MAX_LAYERS];
+  const float* s_ln_b[GFC_LG_MAX_LAYERS];
+  const float* s_ffn3_w[GFC_LG_MAX_LAYERS]; /* [256][512] */
+  const float* s_ffn3_b[GFC_LG_MAX_LAYERS];
+  /* cross block.  c_qkv_w = [to_qk ; to_v] stacked to [512][256] */
+  const float* c_qkv_w[GFC_LG_MAX_LAYERS];
+  const float* c_qkv_b[GFC_LG_MAX_LAYERS];
+  const float* c_out_w[GFC_LG_MAX_LAYERS];
+  const float* c_out_b[GFC_LG_MAX_LAYERS];
+  const float* c_ffn0_w[GFC_LG_MAX_LAYERS];
+  const float* c_ffn0_b[GFC_LG_MAX_LAYERS];
+  const float* c_ln_g[GFC_LG_MAX_LAYERS];
+  const float* c_ln_b[GFC_LG_MAX_LAYERS];
+  const float* c_ffn3_w[GFC_LG_MAX_LAYERS];
+  const float* c_ffn3_b[GFC_LG_MAX_LAYERS];
+  /* assignment head of the last layer (lightglue.py:524) */
+  const float* final_proj_w; /* [256][256] */
+  const float* final_proj_b;
+  const float* matchability_w; /* [256] */
+  const float* matchability_b; /* [1] */
+} gfc_lg_params;
+
+size_t gfc_lg_workspace_bytes(int B, int M, int N);
+
+/* Rotary tables: kpts [rows,2] pixel coords, per image i: rows [row0[i], row0[i]+n[i]) are
+ * normalised with size[i] = (w,h): (k - size/2) / (max(size)/2), projected by Wr [32][2];
+ * cos/sin [rows,64] with each value repeated twice.  lightglue.py:28-40,53-66. */
+int gfc_lg_posenc(const float* kpts, const float* sizes, const int32_t* row0, const int32_t* n, int n_images,
+                  int max_n, const float* wr, float* cos_out, float* sin_out, void* stream);
+
+/* log assignment [B,M+1,N+1] from sim [B,M,N] (ld = N), z0 [B,M], z1 [B,N]:
+ * sigmoid_log_double_softmax, lightglue.py:257-269.  ws: 2*B*(M+N) floats. */
+int gfc_lg_log_assignment(const float* sim, const float* z0, const float* z1, int B, int M, int N, float* out,
+                          void* ws, size_t ws_bytes, void* stream);
+
+/* Mutual arg-max matches from a log assignment [B,M+1,N+1]: filter_matches, lightglue.py:294-319.
+ * m0 [B,M] int64, m1 [B,N] int64, ms0 [B,M], ms1 [B,N].  Ties: first index.
+ * ws: B*(M+N)*(4+4) bytes. */
+int gfc_lg_filter_matches(const float* scores, int B, int M, int N, float threshold, int64_t* m0, int64_t* m1,
+                          float* ms0, float* ms1, void* ws, size_t ws_bytes, void* stream);
+
+/* Whole matcher: LightGlue.forward (lightglue.py:422-553) with early stop / pruning disabled.
+ * kpts0 [B,M,2], kpts1 [B,N,2] (pixel coords), desc0 [B,M,Din], desc1 [B,N,Din],
+ * size0/size1 [B,2] = (w,h) floats.  Outputs as filter_matches + log_assignment [B,M+1,N+1]
+ * + ref_desc0 [B,M,256], ref_desc1 [B,N,256] (last-layer descriptors, lightglue.py:495-498). */
+int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,
+                   const float* desc1, const float* size0, const float* size1, int B, int M, int N,
+                   float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
+                   float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFC_AMD_H */

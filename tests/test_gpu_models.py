@@ -1,0 +1,285 @@
+"""GPU parity of the boundary modules (extractor / matcher / pipeline) against (a) the golden
+vectors produced by the reference's own modules and (b) the CPU oracle at BASELINE.json's full
+sizes, plus size-independent properties.  Indices and counts bit-exact, floats within 1e-4."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from glue_factory_colon_amd import lightglue, lightglue_pretrained, superpoint, superpoint_open  # noqa: E402
+from glue_factory_colon_amd import synthetic, weights  # noqa: E402
+from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline  # noqa: E402
+from oracle import lightglue as olg  # noqa: E402
+from oracle import superpoint as osp  # noqa: E402
+
+DEV = "cuda"
+TOL = 1e-4
+
+
+def maxerr(a, b):
+    assert tuple(a.shape) == tuple(b.shape), (a.shape, b.shape)
+    return (a.double().cpu() - b.double().cpu()).abs().max().item() if a.numel() else 0.0
+
+
+def spo(**conf):
+    return superpoint_open.SuperPoint({"weights": "synthetic", **conf}).eval().to(DEV)
+
+
+# ----------------------------------------------------------------------- SuperPoint-open
+def test_superpoint_open_dense_golden(golden):
+    g = golden("superpoint_open")
+    m = spo(max_num_keypoints=150, detection_threshold=0.0, nms_radius=3, dense_outputs=True)
+    m._packed = m._pack(torch.device(DEV, 0))
+    heat, raw = m._runner.dense(m._packed, g["image"].to(DEV))
+    assert maxerr(heat, g["heatmap"]) < 1e-5
+    pred = m({"image": g["image"][:1].to(DEV)})
+    assert maxerr(pred["dense_descriptors"][0], g["dense_desc_0"]) < TOL
+    nms = m._runner.nms(g["heatmap"].to(DEV), 3, 0)
+    assert torch.equal(nms.cpu(), g["nms_r3"])  # stage-isolated: reference heat-map in, bit-exact out
+
+
+def test_superpoint_open_outputs_golden(golden):
+    g = golden("superpoint_open")
+    m = spo(max_num_keypoints=150, detection_threshold=0.0, nms_radius=3)
+    for i in range(2):
+        p = m({"image": g["image"][i:i + 1].to(DEV)})
+        assert p["keypoints"].shape == (1, 150, 2) and p["descriptors"].shape == (1, 150, 256)
+        assert torch.equal(p["keypoints"][0].cpu(), g[f"k150_kpts_{i}"])
+        assert maxerr(p["keypoint_scores"][0], g[f"k150_scores_{i}"]) < 1e-5
+        assert maxerr(p["descriptors"][0], g[f"k150_desc_{i}"]) < TOL
+        assert p["extractor_core_time_ms"].shape == (1,)
+    # fewer detections than k: all of them, row-major
+    p = spo(max_num_keypoints=4096, detection_threshold=0.0, nms_radius=4)({"image": g["image"][:1].to(DEV)})
+    assert torch.equal(p["keypoints"][0].cpu(), g["k4096_r4_kpts_0"])
+    assert maxerr(p["descriptors"][0], g["k4096_r4_desc_0"]) < TOL
+    # RGB input, threshold, no NMS, wider border
+    p = spo(max_num_keypoints=100, detection_threshold=0.02, nms_radius=0, remove_borders=6)(
+        {"image": g["image_rgb"].to(DEV)})
+    assert torch.equal(p["keypoints"][0].cpu(), g["rgb_r0_kpts"])
+    assert maxerr(p["keypoint_scores"][0], g["rgb_r0_scores"]) < 1e-5
+    assert maxerr(p["descriptors"][0], g["rgb_r0_desc"]) < TOL
+    # batched with force_num_keypoints
+    p = spo(max_num_keypoints=64, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)(
+        {"image": g["image"].to(DEV)})
+    assert torch.equal(p["keypoints"].cpu(), g["b2_k64_kpts"])
+    assert maxerr(p["descriptors"], g["b2_k64_desc"]) < TOL
+
+
+def test_superpoint_open_padding_and_errors():
+    img = synthetic.synthetic_images(2, 64, 96, seed=3).to(DEV)
+    m = spo(max_num_keypoints=512, detection_threshold=0.0, nms_radius=4, force_num_keypoints=True)
+    p = m({"image": img})
+    assert p["keypoints"].shape == (2, 512, 2) and p["descriptors"].shape == (2, 512, 256)
+    n_real = (p["keypoint_scores"] > 0).sum(1)
+    assert (n_real < 512).all() and (n_real > 0).all()  # padded with random points, zero scores
+    assert torch.allclose(p["descriptors"].norm(dim=-1), torch.ones(2, 512, device=DEV), atol=1e-5)
+    with pytest.raises(AssertionError, match="Missing key image"):
+        m({"img": img})
+    with pytest.raises(Exception, match="cuda"):
+        m({"image": img.cpu()})
+    with pytest.raises(RuntimeError):  # ragged batch without force_num_keypoints (the reference cannot stack either)
+        im2 = img.clone()
+        im2[1] = 0.5
+        spo(max_num_keypoints=512, detection_threshold=0.0)({"image": im2})
+
+
+# -------------------------------------------------------------------- SuperPoint official
+def test_superpoint_official_golden(golden):
+    g = golden("superpoint_official")
+    img = g["image"].to(DEV)
+
+    def sp(**conf):
+        return superpoint.SuperPoint({"weights": "synthetic", **conf}).eval().to(DEV)
+
+    p = sp(sparse_outputs=False)({"image": img})
+    assert maxerr(p["keypoint_scores"], g["heatmap"]) < 1e-5
+    assert maxerr(p["descriptors"], g["dense_desc"]) < TOL
+    for legacy, tag in ((True, "legacy"), (False, "fixed")):
+        p = sp(max_num_keypoints=120, detection_threshold=0.0, nms_radius=3, legacy_sampling=legacy)({"image": img})
+        assert torch.equal(p["keypoints"][0].cpu(), g[f"{tag}_kpts"])
+        assert maxerr(p["keypoint_scores"][0], g[f"{tag}_scores"]) < 1e-5
+        assert maxerr(p["descriptors"][0], g[f"{tag}_desc"]) < TOL
+    p = sp(max_num_keypoints=-1, detection_threshold=0.01, nms_radius=4)(
+        {"image": img, "image_size": g["sized_image_size"].to(DEV)})
+    assert torch.equal(p["keypoints"][0].cpu(), g["sized_kpts"])
+    assert maxerr(p["descriptors"][0], g["sized_desc"]) < TOL
+
+
+# ------------------------------------------------------------------------------ LightGlue
+def lg_data(g, sl=slice(None), prefix=""):
+    size = g["image_size"][sl].to(DEV)
+    return {"keypoints0": g[prefix + "keypoints0"][sl].to(DEV), "keypoints1": g[prefix + "keypoints1"][sl].to(DEV),
+            "descriptors0": g[prefix + "descriptors0"][sl].to(DEV),
+            "descriptors1": g[prefix + "descriptors1"][sl].to(DEV),
+            "view0": {"image_size": size}, "view1": {"image_size": size}}
+
+
+def check_lg(pred, g, tag, atol_la=2e-4):
+    assert pred["matches0"].dtype == torch.int64
+    assert torch.equal(pred["matches0"].cpu(), g[tag + "matches0"])
+    assert torch.equal(pred["matches1"].cpu(), g[tag + "matches1"])
+    assert maxerr(pred["matching_scores0"], g[tag + "matching_scores0"]) < TOL
+    assert maxerr(pred["matching_scores1"], g[tag + "matching_scores1"]) < TOL
+    la, ref = pred["log_assignment"].cpu(), g[tag + "log_assignment"]
+    assert la.shape == ref.shape
+    assert ((la - ref).abs() <= atol_la + 1e-5 * ref.abs()).all(), (la - ref).abs().max()
+
+
+def test_lightglue_golden(golden):
+    g = golden("lightglue")
+    m = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+    pred = m(lg_data(g))
+    check_lg(pred, g, "b2_")
+    assert maxerr(pred["ref_descriptors0"], g["b2_ref_descriptors0"]) < 2e-4
+    assert maxerr(pred["ref_descriptors1"], g["b2_ref_descriptors1"]) < 2e-4
+    assert torch.equal(pred["prune0"].cpu(), g["b2_prune0"])
+    m0 = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.0}).eval().to(DEV)
+    pred = m0(lg_data(g))
+    assert torch.equal(pred["matches0"].cpu(), g["th0_matches0"])
+    assert torch.equal(pred["matches1"].cpu(), g["th0_matches1"])
+    # ragged pair (M != N)
+    d = lg_data(g, slice(0, 1))
+    d["keypoints0"], d["descriptors0"] = d["keypoints0"][:, :100].contiguous(), d["descriptors0"][:, :100].contiguous()
+    check_lg(m(d), g, "ragged_")
+
+
+def test_lightglue_128d_and_pretrained_wrapper(golden):
+    g = golden("lightglue")
+    m = lightglue_pretrained.LightGlue({"features": "disk", "weights": "synthetic", "filter_threshold": 0.1})
+    m = m.eval().to(DEV)
+    assert m.is_initialized()
+    size = g["image_size"][:1].to(DEV)
+    d = {"keypoints0": g["d128_keypoints0"].to(DEV), "keypoints1": g["d128_keypoints1"].to(DEV),
+         "descriptors0": g["d128_descriptors0"].to(DEV), "descriptors1": g["d128_descriptors1"].to(DEV),
+         "view0": {"image_size": size}, "view1": {"image_size": size}}
+    check_lg(m(d), g, "d128_")
+    with pytest.raises(AssertionError, match="Missing key"):
+        m({k: v for k, v in d.items() if k != "descriptors1"})
+
+
+def test_lightglue_layer0_golden(golden):
+    """First self block + first full layer in isolation (rotary, attention, FFN) through gfc_lg_forward
+    with a 1-layer parameter set."""
+    g = golden("lightglue")
+    sd = weights.lightglue_state_dict(0)
+    m = lightglue.LightGlue({"n_layers": 1, "filter_threshold": 0.1}).eval()
+    m.load_state_dict({k: v for k, v in sd.items()
+                       if not any(f".{i}." in k for i in range(1, 9))}, strict=False)
+    m = m.to(DEV)
+    pred = m(lg_data(g))
+    assert maxerr(pred["ref_descriptors0"][:, 0], g["layer0_desc0"]) < 5e-5
+    assert maxerr(pred["ref_descriptors1"][:, 0], g["layer0_desc1"]) < 5e-5
+
+
+def test_lightglue_empty_set():
+    m = lightglue.LightGlue({"weights": "synthetic"}).eval().to(DEV)
+    size = torch.tensor([[64.0, 48.0]], device=DEV)
+    d = {"keypoints0": torch.zeros((1, 0, 2), device=DEV), "keypoints1": torch.rand((1, 5, 2), device=DEV) * 40,
+         "descriptors0": torch.zeros((1, 0, 256), device=DEV), "descriptors1": torch.randn((1, 5, 256), device=DEV),
+         "view0": {"image_size": size}, "view1": {"image_size": size}}
+    p = m(d)
+    assert p["matches0"].shape == (1, 0) and (p["matches1"] == -1).all() and p["log_assignment"].shape == (1, 1, 6)
+
+
+# ------------------------------------------------------------------------------- pipeline
+PIPE_CONF = {"extractor": {"name": "extractors.superpoint_open", "weights": "synthetic", "max_num_keypoints": 256,
+                           "detection_threshold": 0.0, "nms_radius": 3},
+             "matcher": {"name": "matchers.lightglue", "weights": "synthetic", "filter_threshold": 0.1, "flash": False}}
+
+
+def test_pipeline_golden(golden):
+    g = golden("pipeline")
+    pipe = TwoViewPipeline(PIPE_CONF).eval().to(DEV)
+    assert pipe.is_initialized()
+    for tag in ("syn", "boat"):
+        v0, v1 = g.image(tag + "_image0").to(DEV), g.image(tag + "_image1").to(DEV)
+        s0 = torch.tensor([[float(v0.shape[-1]), float(v0.shape[-2])]], device=DEV)
+        s1 = torch.tensor([[float(v1.shape[-1]), float(v1.shape[-2])]], device=DEV)
+        pred = pipe({"view0": {"image": v0, "image_size": s0}, "view1": {"image": v1, "image_size": s1}})
+        for key in ("keypoints0", "keypoints1", "matches0", "matches1"):
+            assert torch.equal(pred[key].cpu(), g[f"{tag}_{key}"]), (tag, key)
+        for key in ("keypoint_scores0", "keypoint_scores1", "matching_scores0", "matching_scores1"):
+            assert maxerr(pred[key], g[f"{tag}_{key}"]) < TOL, (tag, key)
+        if tag == "syn":
+            assert maxerr(pred["descriptors0"], g["syn_descriptors0"]) < TOL
+            assert set(g["syn_pred_keys"].tolist()) <= set(pred.keys()) | {"extractor_memory_mb", "matcher_memory_mb"}
+            assert (pred["matches0"] >= 0).sum() > 50
+
+
+# ---------------------------------------------------------------- full size (BASELINE C2)
+@pytest.fixture(scope="module")
+def vga_case():
+    v0, v1 = synthetic.synthetic_pairs(2, 480, 640, seed=1234)
+    return v0, v1
+
+
+def test_vga_1024_against_oracle(vga_case):
+    """480x640, 1024 keypoints, batch of 2 pairs (4 images): HIP path vs CPU oracle on the same inputs."""
+    v0, v1 = vga_case
+    conf = dict(max_num_keypoints=1024, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    ext = spo(**conf)
+    imgs = torch.cat([v0, v1], 0)
+    p = ext({"image": imgs.to(DEV)})
+    o = osp.extract(weights.superpoint_open_state_dict(0), imgs, "open", nms_radius=3, max_num_keypoints=1024,
+                    detection_threshold=0.0)
+    okp, osc, ode = torch.stack(o["keypoints"]), torch.stack(o["keypoint_scores"]), torch.stack(o["descriptors"])
+    heat, _ = ext._runner.dense(ext._packed, imgs.to(DEV))
+    assert maxerr(heat, o["heatmap"]) < 1e-5
+    # stage-isolated: the oracle's heat-map through the HIP NMS + select must be bit-exact
+    nms = ext._runner.nms(o["heatmap"].to(DEV), 3, 4)
+    assert torch.equal(nms.cpu(), o["nms"])
+    kp, sc, cnt = ext._runner.select(nms, 0.0, 1024)
+    assert cnt.tolist() == [1024] * 4
+    assert torch.equal(kp.cpu() + 0.5, okp) and torch.equal(sc.cpu(), osc)
+    # end to end (own convolutions): identical key-point sets, scores / descriptors within tolerance
+    assert torch.equal(p["keypoints"].cpu(), okp)
+    assert maxerr(p["keypoint_scores"], osc) < 1e-5
+    assert maxerr(p["descriptors"], ode) < TOL
+    # matcher on the oracle's features (stage isolated) and on its own (end to end)
+    lgm = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+    size = torch.tensor([[640.0, 480.0]] * 2)
+    ref = olg.match(weights.lightglue_state_dict(0), okp[:2], okp[2:], ode[:2], ode[2:], size, size,
+                    filter_threshold=0.1)
+    for k0, k1, d0, d1 in ((okp[:2], okp[2:], ode[:2], ode[2:]),
+                           (p["keypoints"][:2], p["keypoints"][2:], p["descriptors"][:2], p["descriptors"][2:])):
+        pred = lgm({"keypoints0": k0.to(DEV), "keypoints1": k1.to(DEV), "descriptors0": d0.to(DEV).contiguous(),
+                    "descriptors1": d1.to(DEV).contiguous(), "view0": {"image_size": size.to(DEV)},
+                    "view1": {"image_size": size.to(DEV)}})
+        assert torch.equal(pred["matches0"].cpu(), ref["matches0"])
+        assert torch.equal(pred["matches1"].cpu(), ref["matches1"])
+        assert maxerr(pred["matching_scores0"], ref["matching_scores0"]) < TOL
+        assert (pred["matches0"] >= 0).sum() > 1000  # ~750 matches per pair on the shifted copy
+    # size-independent properties
+    m0, m1 = pred["matches0"], pred["matches1"]
+    idx = torch.arange(1024, device=DEV)[None].expand(2, -1)
+    ok = m0 >= 0
+    assert (m1.gather(1, m0.clamp(min=0))[ok] == idx[ok]).all()  # mutual consistency
+    la = pred["log_assignment"]
+    assert (la[:, :-1, :].exp().sum(2) <= 1 + 1e-4).all() and (la[:, :, :-1].exp().sum(1) <= 1 + 1e-4).all()
+    shifted = p["keypoints"][:2] + torch.tensor([16.0, 8.0], device=DEV)
+    hit = (shifted[ok] - p["keypoints"][2:].gather(1, m0.clamp(min=0)[..., None].expand(-1, -1, 2))[ok]).abs().max(-1)
+    assert (hit.values < 0.5).float().mean() > 0.95  # matches follow the known shift
+    assert (p["keypoint_scores"][:, :-1] >= p["keypoint_scores"][:, 1:]).all()  # sorted by score
+    assert torch.allclose(p["descriptors"].norm(dim=-1), torch.ones(4, 1024, device=DEV), atol=1e-5)
+
+
+def test_large_2048_properties():
+    """BASELINE config 4 shape (1024x1024, 2048 keypoints), one pair: round-trip properties only."""
+    v0, v1 = synthetic.synthetic_pairs(1, 1024, 1024, seed=99)
+    pipe = TwoViewPipeline({"extractor": {**PIPE_CONF["extractor"], "max_num_keypoints": 2048},
+                            "matcher": PIPE_CONF["matcher"]}).eval().to(DEV)
+    size = torch.tensor([[1024.0, 1024.0]], device=DEV)
+    pred = pipe({"view0": {"image": v0.to(DEV), "image_size": size}, "view1": {"image": v1.to(DEV), "image_size": size}})
+    assert pred["keypoints0"].shape == (1, 2048, 2) and pred["log_assignment"].shape == (1, 2049, 2049)
+    m0, m1 = pred["matches0"], pred["matches1"]
+    ok = m0 >= 0
+    assert ok.sum() > 1000
+    idx = torch.arange(2048, device=DEV)[None]
+    assert (m1.gather(1, m0.clamp(min=0))[ok] == idx[ok]).all()
+    d = pred["keypoints0"][ok] + torch.tensor([16.0, 8.0], device=DEV) - pred["keypoints1"][0][m0[ok]]
+    assert (d.abs().max(-1).values < 0.5).float().mean() > 0.95
+    # idempotence of NMS: suppressing an already suppressed map changes nothing
+    ext = pipe.extractor
+    heat, _ = ext._runner.dense(ext._packed, v0.to(DEV))
+    once = ext._runner.nms(heat, 3, 0)
+    assert torch.equal(ext._runner.nms(once, 3, 0), once)

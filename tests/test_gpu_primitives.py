@@ -1,0 +1,362 @@
+"""GPU parity of every exported kernel in isolation (through the C ABI), against the oracle /
+plain torch fp32 on the same seeded inputs.  Integer / index outputs bit-exact; floating point
+within 1e-4 (north-star tolerance), in practice ~1e-6."""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from glue_factory_colon_amd import _native as nat  # noqa: E402
+from oracle import lightglue as olg  # noqa: E402
+from oracle import superpoint as osp  # noqa: E402
+
+DEV = "cuda"
+
+
+def st():
+    return nat.stream_ptr(torch.device(DEV))
+
+
+def maxerr(a, b):
+    return (a.double().cpu() - b.double().cpu()).abs().max().item()
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ------------------------------------------------------------------------------- conv3x3
+@pytest.mark.parametrize("cin,cout,h,w,pool,bn", [(64, 64, 32, 48, True, True), (64, 128, 30, 40, False, True),
+                                                   (128, 128, 17, 23, True, False), (128, 512, 15, 20, False, True),
+                                                   (1, 64, 21, 35, False, True), (64, 64, 33, 47, True, True)])
+def test_conv3x3(cin, cout, h, w, pool, bn):
+    lib = nat.lib()
+    g = gen(cin + cout + h)
+    b = 2
+    x = torch.randn((b, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn((cout,), generator=g) * 0.1
+    scale = torch.rand((cout,), generator=g) + 0.5 if bn else None
+    shift = torch.randn((cout,), generator=g) * 0.1 if bn else None
+    scale_neg = scale
+    if bn:
+        scale_neg = scale.clone()
+        scale_neg[::3] *= -1  # negative BN gains: pooling must come after the affine
+    ref = F.relu(F.conv2d(x, wt, bias, padding=1))
+    if bn:
+        ref = ref * scale_neg[None, :, None, None] + shift[None, :, None, None]
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wd = wt.to(DEV).contiguous()
+    wp = torch.empty((9, cout, cin), device=DEV)
+    nat.check(lib.gfc_pack_conv3x3(nat.ptr(wd), nat.ptr(wp), cout, cin, st()), "pack")
+    assert torch.equal(wp.cpu(), wt.permute(2, 3, 0, 1).reshape(9, cout, cin))
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
+    nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(bias.to(DEV)),
+                              nat.ptr(scale_neg.to(DEV)) if bn else None, nat.ptr(shift.to(DEV)) if bn else None,
+                              nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()), "conv")
+    torch.cuda.synchronize()
+    assert maxerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
+def test_conv3x3_rejects_bad_shapes():
+    lib = nat.lib()
+    x = torch.zeros(16, device=DEV)
+    assert lib.gfc_conv3x3(nat.ptr(x), nat.ptr(x), nat.ptr(x), None, None, nat.ptr(x), 1, 8, 8, 48, 64, 1, 0, st()) == 3
+    assert lib.gfc_conv3x3(None, nat.ptr(x), nat.ptr(x), None, None, nat.ptr(x), 1, 8, 8, 64, 64, 1, 0, st()) == 1
+
+
+# -------------------------------------------------------------------------------- linear
+def run_linear(a0, w, bias=None, a1=None, scale=None, shift=None, alpha=1.0, residual=None, cos=None, sin=None,
+               rot_cols=0, ldy=None):
+    lib = nat.lib()
+    m, n = a0.shape[0], w.shape[0]
+    ldy = ldy or n
+    y = torch.full((m, ldy), float("nan"), device=DEV)
+    d = lambda t: None if t is None else t.to(DEV).contiguous()  # noqa: E731
+    a0d, a1d, wd, bd, scd, shd, rd, cd, sd = map(d, (a0, a1, w, bias, scale, shift, residual, cos, sin))
+    if rd is not None:
+        y[:, :n] = rd
+        rd = y
+    nat.check(lib.gfc_linear(nat.ptr(a0d), a0.shape[1], a0.shape[1], nat.ptr(a1d), 0 if a1 is None else a1.shape[1],
+                             0 if a1 is None else a1.shape[1], nat.ptr(wd), w.shape[1], nat.ptr(bd), nat.ptr(scd),
+                             nat.ptr(shd), alpha, nat.ptr(rd), nat.ptr(cd), nat.ptr(sd), rot_cols, nat.ptr(y), ldy, m,
+                             n, st()), "linear")
+    torch.cuda.synchronize()
+    return y[:, :n].cpu()
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 256, 256), (129, 65, 256), (1000, 768, 256), (64, 512, 512), (5, 256, 128)])
+def test_linear_plain(m, n, k):
+    g = gen(m + n)
+    a = torch.randn((m, k), generator=g)
+    w = torch.randn((n, k), generator=g) / k ** 0.5
+    b = torch.randn((n,), generator=g)
+    assert maxerr(run_linear(a, w, b), F.linear(a, w, b)) < 2e-5
+    assert maxerr(run_linear(a, w, b, alpha=0.25), F.linear(a, w, b) / 4) < 1e-5
+
+
+def test_linear_concat_residual_affine():
+    g = gen(5)
+    m = 333
+    x, msg = torch.randn((m, 256), generator=g), torch.randn((m, 256), generator=g)
+    w = torch.randn((512, 512), generator=g) / 512 ** 0.5
+    b = torch.randn((512,), generator=g)
+    ref = F.linear(torch.cat([x, msg], -1), w, b)
+    assert maxerr(run_linear(x, w, b, a1=msg), ref) < 2e-5
+    w3 = torch.randn((256, 512), generator=g) / 512 ** 0.5
+    h = torch.randn((m, 512), generator=g)
+    assert maxerr(run_linear(h, w3, b[:256], residual=x), x + F.linear(h, w3, b[:256])) < 2e-5
+    sc, sh = torch.rand((256,), generator=g) + 0.5, torch.randn((256,), generator=g)
+    assert maxerr(run_linear(x, w3[:, :256].contiguous(), b[:256], scale=sc, shift=sh),
+                  F.linear(x, w3[:, :256], b[:256]) * sc + sh) < 2e-5
+    # non-multiple-of-4 output stride (the 65-logit detector head)
+    w65 = torch.randn((65, 256), generator=g) / 16
+    assert maxerr(run_linear(x, w65, b[:65], ldy=65), F.linear(x, w65, b[:65])) < 2e-5
+
+
+def test_linear_rotary():
+    g = gen(9)
+    m = 200
+    x = torch.randn((m, 256), generator=g)
+    w = torch.randn((768, 256), generator=g) / 16
+    b = torch.randn((768,), generator=g) * 0.1
+    ang = torch.randn((m, 32), generator=g) * 2
+    cos = ang.cos().repeat_interleave(2, -1)
+    sin = ang.sin().repeat_interleave(2, -1)
+    y = F.linear(x, w, b)
+    qk = y[:, :512].view(m, 8, 64)
+    enc = torch.stack([cos, sin], 0)[:, :, None]  # [2, m, 1, 64]
+    ref = torch.cat([olg.rotary(enc, qk).reshape(m, 512), y[:, 512:]], -1)
+    out = run_linear(x, w, b, cos=cos, sin=sin, rot_cols=512)
+    assert maxerr(out, ref) < 2e-5
+
+
+def test_batched_nt():
+    lib = nat.lib()
+    g = gen(3)
+    b, m, n, k = 3, 150, 97, 256
+    a = torch.randn((b, m, k), generator=g).to(DEV)
+    c = torch.randn((b, n, k), generator=g).to(DEV)
+    y = torch.full((b, m + 1, n + 1), 7.0, device=DEV)
+    nat.check(lib.gfc_batched_nt(nat.ptr(a), k, m * k, nat.ptr(c), k, n * k, nat.ptr(y), n + 1, (m + 1) * (n + 1), m,
+                                 n, k, b, st()), "batched_nt")
+    torch.cuda.synchronize()
+    ref = torch.einsum("bmd,bnd->bmn", a.cpu(), c.cpu())
+    assert maxerr(y[:, :m, :n], ref) < 5e-5
+    assert (y[:, m, :] == 7).all() and (y[:, :, n] == 7).all()  # border untouched
+
+
+# ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("shapes", [[(128, 128)], [(100, 161), (161, 100)], [(1, 1), (300, 33), (64, 257)],
+                                    [(1024, 1024)]])
+def test_attention(shapes):
+    lib = nat.lib()
+    g = gen(len(shapes) + shapes[0][0])
+    rows = sum(max(nq, nk) for nq, nk in shapes)
+    q = torch.randn((rows, 256), generator=g) * 1.5
+    k = torch.randn((rows, 256), generator=g) * 1.5
+    v = torch.randn((rows, 256), generator=g)
+    probs, r0 = [], 0
+    for nq, nk in shapes:
+        probs.append([r0, nq, r0, nk])
+        r0 += max(nq, nk)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o = torch.full((rows, 256), float("nan"), device=DEV)
+    pt = torch.tensor(probs, dtype=torch.int32, device=DEV)
+    nat.check(lib.gfc_attention(nat.ptr(qd), 256, nat.ptr(kd), 256, nat.ptr(vd), 256, nat.ptr(o), 256, nat.ptr(pt),
+                                len(shapes), max(s[0] for s in shapes), 4, 0.125, st()), "attention")
+    torch.cuda.synchronize()
+    o = o.cpu()
+    for r, nq, _, nk in probs:
+        qq = q[r:r + nq].view(nq, 4, 64).transpose(0, 1)
+        kk = k[r:r + nk].view(nk, 4, 64).transpose(0, 1)
+        vv = v[r:r + nk].view(nk, 4, 64).transpose(0, 1)
+        ref = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(nq, 256)
+        assert maxerr(o[r:r + nq], ref) < 2e-5
+        if nq < max(nq, nk):
+            assert torch.isnan(o[r + nq:r + max(nq, nk)]).all()  # rows of other problems untouched
+
+
+def test_attention_peaky_rows():
+    """A spiked key forces the running-max rescale branch at a chosen tile (online softmax)."""
+    lib = nat.lib()
+    g = gen(77)
+    n = 320
+    q = torch.randn((n, 256), generator=g)
+    k = torch.randn((n, 256), generator=g)
+    v = torch.randn((n, 256), generator=g)
+    k[200] = q[5] * 6  # late, very large score for query 5
+    k[3] = q[9] * 6    # early spike for query 9
+    o = torch.empty((n, 256), device=DEV)
+    pt = torch.tensor([[0, n, 0, n]], dtype=torch.int32, device=DEV)
+    nat.check(lib.gfc_attention(nat.ptr(q.to(DEV)), 256, nat.ptr(k.to(DEV)), 256, nat.ptr(v.to(DEV)), 256, nat.ptr(o),
+                                256, nat.ptr(pt), 1, n, 4, 0.125, st()), "attention")
+    qq, kk, vv = (t.double().view(n, 4, 64).transpose(0, 1) for t in (q, k, v))
+    ref = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(n, 256)
+    assert maxerr(o, ref) < 2e-5
+
+
+def test_layernorm_gelu():
+    lib = nat.lib()
+    g = gen(4)
+    x = torch.randn((301, 512), generator=g) * 3 + 0.5
+    gamma, beta = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g)
+    xd = x.to(DEV)
+    nat.check(lib.gfc_layernorm_gelu(nat.ptr(xd), 512, 301, 512, nat.ptr(gamma.to(DEV)), nat.ptr(beta.to(DEV)), st()),
+              "ln")
+    ref = F.gelu(F.layer_norm(x, (512,), gamma, beta, 1e-5))
+    assert maxerr(xd, ref) < 2e-5
+
+
+# ---------------------------------------------------------------------------- detection
+@pytest.mark.parametrize("r", [0, 1, 3, 4])
+def test_nms_golden_bit_exact(golden, r):
+    lib = nat.lib()
+    gd = golden("nms")
+    s = gd[f"in_r{r}"].to(DEV)
+    out = torch.empty_like(s)
+    nat.check(lib.gfc_sp_nms(nat.ptr(s), s.shape[0], s.shape[1], s.shape[2], r, 0, None, nat.ptr(out), st()), "nms")
+    assert torch.equal(out.cpu(), gd[f"out_r{r}"])
+
+
+@pytest.mark.parametrize("r,h,w", [(3, 480, 640), (4, 100, 77), (2, 33, 200)])
+def test_nms_large_vs_oracle(r, h, w):
+    lib = nat.lib()
+    g = gen(r * 100 + h)
+    s = torch.rand((2, h, w), generator=g)
+    s[1] = (s[1] * 16).round() / 16  # many exact ties / plateaus
+    s[0, 50:60, 20:60] = 0.5
+    sd = s.to(DEV)
+    out = torch.empty_like(sd)
+    wh = torch.tensor([[w - 5, h - 9], [w, h]], dtype=torch.int32, device=DEV)
+    nat.check(lib.gfc_sp_nms(nat.ptr(sd), 2, h, w, r, 4, nat.ptr(wh), nat.ptr(out), st()), "nms")
+    ref = osp.kill_borders(osp.nms(s, r), 4, wh.cpu().float())
+    assert torch.equal(out.cpu(), ref)
+
+
+def run_select(scores, th, k):
+    from glue_factory_colon_amd._superpoint_common import SuperPointRunner
+
+    kp, sc, cnt = SuperPointRunner().select(scores.to(DEV).contiguous(), th, k)
+    torch.cuda.synchronize()
+    return kp.cpu(), sc.cpu(), cnt.cpu()
+
+
+@pytest.mark.parametrize("k", [50, 1024, 5000, None])
+def test_select_bit_exact(k):
+    g = gen(12)
+    h, w = 120, 160
+    s = torch.rand((3, h, w), generator=g)
+    s = osp.kill_borders(osp.nms(s, 3), 4)
+    s[2] = -1.0
+    s[2, 40, 50] = 0.25  # a single candidate
+    kp, sc, cnt = run_select(s, 0.0, k)
+    for i in range(3):
+        xy, val = osp.select_keypoints(s[i], 0.0, k)
+        n = int(cnt[i])
+        assert n == len(val)
+        assert torch.equal(kp[i, :n], xy) and torch.equal(sc[i, :n], val)
+
+
+def test_select_ties_and_empty():
+    """Equal scores: lower linear index first (what torch.topk on CPU returns for these inputs is
+    not contractual; the HIP rule is documented in the header) -- here checked against a stable sort."""
+    h, w = 64, 96
+    s = torch.full((2, h, w), -1.0)
+    s[0, 8:56:4, 8:88:4] = 0.5
+    s[0, 20, 20] = 0.9
+    kp, sc, cnt = run_select(s, 0.0, 40)
+    assert cnt.tolist() == [40, 0]
+    ys, xs = torch.where(s[0] > 0)
+    order = torch.argsort(-s[0][ys, xs], stable=True)[:40]
+    assert torch.equal(kp[0, :40], torch.stack([xs[order], ys[order]], -1).float())
+    assert (sc[1] == 0).all()
+
+
+@pytest.mark.parametrize("mode,name", [(0, "open"), (1, "legacy"), (2, "fixed")])
+def test_sample_descriptors(mode, name):
+    lib = nat.lib()
+    g = gen(21 + mode)
+    b, h8, w8, n = 2, 15, 20, 300
+    dense = torch.randn((b, 256, h8, w8), generator=g)
+    kp = torch.stack([torch.randint(0, w8 * 8, (b, n), generator=g), torch.randint(0, h8 * 8, (b, n), generator=g)],
+                     -1).float()
+    kp[0, 0] = torch.tensor([0.0, 0.0])
+    kp[0, 1] = torch.tensor([w8 * 8 - 1.0, h8 * 8 - 1.0])
+    ref = osp.sample_descriptors(kp, F.normalize(dense, dim=1), 8, name)
+    raw = dense.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = torch.empty((b, n, 256), device=DEV)
+    kout = torch.empty((b, n, 2), device=DEV)
+    nat.check(lib.gfc_sp_sample(nat.ptr(raw), b, h8, w8, 256, nat.ptr(kp.to(DEV)), None, n, mode, nat.ptr(out),
+                                nat.ptr(kout), st()), "sample")
+    assert maxerr(out, ref) < 1e-5
+    assert torch.equal(kout.cpu(), kp + 0.5)
+
+
+# ---------------------------------------------------------------------------- assignment
+def test_log_assignment_and_filter_golden(golden):
+    lib = nat.lib()
+    gd = golden("assignment")
+    sim, z0, z1 = gd["sim"], gd["z0"], gd["z1"]
+    b, m, n = sim.shape
+    out = torch.empty((b, m + 1, n + 1), device=DEV)
+    ws = torch.empty(2 * b * (m + n) * 4, dtype=torch.uint8, device=DEV)
+    nat.check(lib.gfc_lg_log_assignment(nat.ptr(sim.to(DEV)), nat.ptr(z0.reshape(b, m).contiguous().to(DEV)),
+                                        nat.ptr(z1.reshape(b, n).contiguous().to(DEV)), b, m, n, nat.ptr(out),
+                                        nat.ptr(ws), ws.numel(), st()), "log_assignment")
+    assert maxerr(out, gd["log_assignment"]) < 1e-5
+    for th, tag in ((0.0, "0p0"), (0.1, "0p1"), (0.5, "0p5")):
+        m0, m1, s0, s1 = run_filter(gd["log_assignment"], th)
+        assert torch.equal(m0, gd[f"m0_{tag}"]) and torch.equal(m1, gd[f"m1_{tag}"])
+        assert maxerr(s0, gd[f"s0_{tag}"]) < 1e-6 and maxerr(s1, gd[f"s1_{tag}"]) < 1e-6
+    m0, m1, _, _ = run_filter(gd["perm_log_assignment"], 0.1)
+    assert torch.equal(m0, gd["perm_m0"]) and torch.equal(m1, gd["perm_m1"])
+
+
+def run_filter(scores, th):
+    lib = nat.lib()
+    b, m, n = scores.shape[0], scores.shape[1] - 1, scores.shape[2] - 1
+    m0 = torch.empty((b, m), dtype=torch.long, device=DEV)
+    m1 = torch.empty((b, n), dtype=torch.long, device=DEV)
+    s0, s1 = torch.empty((b, m), device=DEV), torch.empty((b, n), device=DEV)
+    ws = torch.empty(b * (m + n) * 8, dtype=torch.uint8, device=DEV)
+    nat.check(lib.gfc_lg_filter_matches(nat.ptr(scores.to(DEV).contiguous()), b, m, n, th, nat.ptr(m0), nat.ptr(m1),
+                                        nat.ptr(s0), nat.ptr(s1), nat.ptr(ws), ws.numel(), st()), "filter")
+    torch.cuda.synchronize()
+    return m0.cpu(), m1.cpu(), s0.cpu(), s1.cpu()
+
+
+def test_filter_matches_large_random_bit_exact():
+    g = gen(31)
+    sc = torch.randn((2, 1025, 1025), generator=g)
+    sc = (sc * 8).round() / 8  # heavy ties: first-index arg-max must match torch CPU
+    m0, m1, s0, s1 = run_filter(sc, 0.2)
+    r0, r1, rs0, rs1 = olg.filter_matches(sc, 0.2)
+    assert torch.equal(m0, r0) and torch.equal(m1, r1)
+    assert maxerr(s0, rs0) < 1e-6 and maxerr(s1, rs1) < 1e-6
+
+
+def test_posenc(golden):
+    lib = nat.lib()
+    gd = golden("lightglue")
+    kp = gd["keypoints0"]  # [2,160,2]
+    b, n, _ = kp.shape
+    from glue_factory_colon_amd import weights
+
+    wr = weights.lightglue_state_dict(0)["posenc.Wr.weight"]
+    cos = torch.empty((b * n, 64), device=DEV)
+    sin = torch.empty((b * n, 64), device=DEV)
+    row0 = torch.arange(b, dtype=torch.int32, device=DEV) * n
+    cnt = torch.full((b,), n, dtype=torch.int32, device=DEV)
+    nat.check(lib.gfc_lg_posenc(nat.ptr(kp.reshape(-1, 2).contiguous().to(DEV)), nat.ptr(gd["image_size"].to(DEV)),
+                                nat.ptr(row0), nat.ptr(cnt), b, n, nat.ptr(wr.to(DEV).contiguous()), nat.ptr(cos),
+                                nat.ptr(sin), st()), "posenc")
+    enc = gd["enc0"]  # [2,B,1,N,64]
+    assert maxerr(cos.view(b, n, 64), enc[0, :, 0]) < 1e-5
+    assert maxerr(sin.view(b, n, 64), enc[1, :, 0]) < 1e-5

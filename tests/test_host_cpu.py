@@ -1,0 +1,197 @@
+"""CPU-side checks (no GPU, no compute calls into the HIP library): the C-ABI library loads and
+exports every declared symbol, the boundary modules mirror the reference's module contract, the
+product path refuses CPU tensors (no fallback), weight packing order, sharding helpers."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from glue_factory_colon_amd import _native as nat
+from glue_factory_colon_amd import base_model, lightglue, lightglue_pretrained, registry, sharding, superpoint
+from glue_factory_colon_amd import superpoint_open, synthetic, weights
+from glue_factory_colon_amd._superpoint_common import fold_bn, pad_random_c
+from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "gfc_amd.h")).read()
+    declared = set(re.findall(r"\b(gfc_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 18
+    lib = nat.lib()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in gfc_amd.h but not exported"
+    assert declared == set(nat.SIGNATURES), declared ^ set(nat.SIGNATURES)
+    assert b"gfx950" in lib.gfc_version()
+
+
+def test_no_oracle_import_in_product():
+    pkg = os.path.join(ROOT, "glue-factory-colon_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+
+
+def test_conf_merge_and_contract():
+    m = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": 77, "some_unknown_key": 1})
+    assert m.conf.max_num_keypoints == 77 and m.conf.nms_radius == 4 and m.conf.remove_borders == 4
+    assert m.conf.trainable is True and m.conf.name is None  # BaseModel defaults (base_model.py:54-59)
+    assert m.is_initialized()
+    with pytest.raises(AssertionError, match="Missing key image"):
+        m({"not_image": torch.zeros(1)})
+    with pytest.raises(nat.NativeError, match="no CPU implementation"):
+        m({"image": torch.zeros(1, 1, 32, 32)})
+    with pytest.raises(NotImplementedError):
+        m.loss({}, {})
+    un = superpoint_open.SuperPoint({})
+    assert not un.is_initialized()
+    un.load_state_dict(weights.superpoint_open_state_dict(1))
+    assert un.is_initialized()
+    with pytest.raises(FileNotFoundError):
+        superpoint_open.SuperPoint({"weights": "/nonexistent/superpoint_v6_from_tf.pth"})
+
+
+def test_state_dict_key_layouts_match_reference():
+    sd = weights.superpoint_open_state_dict(0)
+    assert len(sd) == 84 and sum(v.numel() for k, v in sd.items() if "num_batches" not in k) > 1_300_000
+    superpoint_open.SuperPoint({}).load_state_dict(sd, strict=True)
+    sd = weights.superpoint_state_dict(0)
+    assert len(sd) == 24
+    superpoint.SuperPoint({}).load_state_dict(sd, strict=True)
+    sd = weights.lightglue_state_dict(0)
+    assert len(sd) == 251  # + confidence_thresholds buffer = 252
+    m = lightglue.LightGlue({})
+    missing = m.load_state_dict(sd, strict=False)
+    assert missing.missing_keys == ["confidence_thresholds"] and not missing.unexpected_keys
+    assert sum(v.numel() for v in m.state_dict().values()) == 11_851_610
+    # legacy checkpoint key names (lightglue.py:394-401)
+    legacy = {k.replace("transformers.3.self_attn", "self_attn.3").replace("transformers.3.cross_attn", "cross_attn.3"): v
+              for k, v in sd.items()}
+    assert any(k.startswith("self_attn.3") for k in legacy)
+    missing = lightglue.LightGlue({}).load_state_dict(legacy, strict=False)
+    assert missing.missing_keys == ["confidence_thresholds"] and not missing.unexpected_keys
+    assert torch.allclose(m.confidence_thresholds[0], torch.tensor(0.9))
+
+
+def test_weights_are_deterministic():
+    a, b = weights.lightglue_state_dict(0), weights.lightglue_state_dict(0)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = weights.lightglue_state_dict(1)
+    assert not torch.equal(a["posenc.Wr.weight"], c["posenc.Wr.weight"])
+    v0, v1 = synthetic.synthetic_pairs(1, 64, 96, seed=5, dx=16, dy=8)
+    assert torch.equal(v1[0, 0, 8:, 16:], v0[0, 0, :-8, :-16])
+
+
+def test_registry_and_pipeline_contract():
+    assert registry.get_model("extractors.superpoint_open") is superpoint_open.SuperPoint
+    assert registry.get_model("gluefactory_nonfree.superpoint") is superpoint.SuperPoint
+    assert registry.get_model("matchers.lightglue") is lightglue.LightGlue
+    assert registry.get_model("matchers.lightglue_pretrained") is lightglue_pretrained.LightGlue
+    assert registry.get_model("glue_factory_colon_amd.lightglue") is lightglue.LightGlue
+    with pytest.raises(RuntimeError, match="not found"):
+        registry.get_model("extractors.aliked")
+    conf = {"extractor": {"name": "gluefactory_nonfree.superpoint", "weights": "synthetic", "max_num_keypoints": 1024,
+                          "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue_pretrained", "features": "superpoint", "weights": "synthetic",
+                        "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}}
+    pipe = TwoViewPipeline(conf)  # the superpoint+lightglue-official.yaml model block
+    assert pipe.is_initialized() and pipe.extractor.conf.legacy_sampling is True
+    with pytest.raises(AssertionError, match="Missing key view1"):
+        pipe({"view0": {}})
+    with pytest.raises(NotImplementedError):
+        TwoViewPipeline({"solver": {"name": "homography_est"}})
+    un = TwoViewPipeline({"extractor": {"name": "extractors.superpoint_open"}, "matcher": {"name": "matchers.lightglue"}})
+    assert not un.is_initialized()
+
+
+def test_lightglue_rejects_out_of_scope_configs():
+    with pytest.raises(NotImplementedError):
+        lightglue.LightGlue({"add_scale_ori": True})
+    m = lightglue.LightGlue({"weights": "synthetic", "depth_confidence": 0.95}).eval()
+    d = {"keypoints0": torch.zeros(1, 4, 2), "keypoints1": torch.zeros(1, 4, 2), "descriptors0": torch.zeros(1, 4, 256),
+         "descriptors1": torch.zeros(1, 4, 256)}
+    with pytest.raises(NotImplementedError, match="adaptive"):
+        m(d)
+    with pytest.raises(AssertionError, match="Missing key descriptors1"):
+        m({k: v for k, v in d.items() if k != "descriptors1"})
+
+
+def test_wqkv_row_permutation_matches_unflatten():
+    """packed row s*256 + h*64 + d must hold state-dict row h*192 + d*3 + s (lightglue.py:157-159)."""
+    d, h, dh = 256, 4, 64
+    w = torch.arange(3 * d, dtype=torch.float32)[:, None].expand(-1, 2)
+    qkv = w[:, 0].view(h, dh, 3)  # unflatten(-1, (h, -1, 3)) of the output channel axis
+    idx = torch.arange(3 * d)
+    s_, rem = idx // d, idx % d
+    src = (rem // dh) * (3 * dh) + (rem % dh) * 3 + s_
+    packed = w[src, 0].view(3, h, dh)
+    for s in range(3):
+        assert torch.equal(packed[s], qkv[..., s])
+
+
+def test_fold_bn_matches_torch_eval_batchnorm():
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn((2, 8, 5, 5), generator=g)
+    w, b = torch.rand(8, generator=g) + 0.5, torch.randn(8, generator=g)
+    mean, var = torch.randn(8, generator=g), torch.rand(8, generator=g) + 0.2
+    a, c = fold_bn(w, b, mean, var, 1e-3)
+    ref = torch.nn.functional.batch_norm(x, mean, var, w, b, False, 0.0, 1e-3)
+    assert (x * a[None, :, None, None] + c[None, :, None, None] - ref).abs().max() < 1e-6
+
+
+def test_pad_random_c_semantics():
+    kp = torch.tensor([[[3.0, 7.0], [10.0, 2.0], [0, 0], [0, 0]], [[0, 0]] * 4])
+    sc = torch.tensor([[0.5, 0.4, 9, 9], [9.0, 9, 9, 9]])
+    out, s = pad_random_c(kp, sc, torch.tensor([2, 0]), 4, 0, 48)
+    assert torch.equal(out[0, :2], kp[0, :2]) and torch.equal(s[0], torch.tensor([0.5, 0.4, 0, 0]))
+    assert (out[0, 2:, 0] >= 3).all() and (out[0, 2:, 0] <= 10).all()  # per-column range of the real points
+    assert (out[0, 2:, 1] >= 2).all() and (out[0, 2:, 1] <= 7).all()
+    assert (out[1] >= 0).all() and (out[1] <= 48).all() and (s[1] == 0).all()  # empty image: bounds fallback
+
+
+def test_shard_partitions():
+    for n, w in ((256, 8), (540, 8), (7, 3), (2, 4)):
+        blocks = [list(sharding.contiguous_shard(n, r, w)) for r in range(w)]
+        assert sorted(sum(blocks, [])) == list(range(n))
+        assert max(map(len, blocks)) - min(map(len, blocks)) <= 1
+        rr = [list(sharding.round_robin_shard(n, r, w)) for r in range(w)]
+        assert sorted(sum(rr, [])) == list(range(n))
+
+
+def test_gather_records_world2_gloo(tmp_path):
+    """The only collective of the path: one gather of fixed-size records, 2 ranks on gloo."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from glue_factory_colon_amd import sharding\n"
+        "rank, world, _ = sharding.init_from_env('gloo')\n"
+        "pairs = list(sharding.contiguous_shard(6, rank, world))\n"
+        "pred = {'matches0': torch.tensor([[p, -1, 2] for p in pairs]), 'keypoints0': torch.ones(len(pairs), 3, 2) * rank,\n"
+        "        'keypoints1': torch.ones(len(pairs), 3, 2), 'matching_scores0': torch.full((len(pairs), 3), 0.5)}\n"
+        "rec = sharding.pack_pair_records(pred, 4)\n"
+        "out = sharding.gather_records(rec)\n"
+        "if rank == 0:\n"
+        "    allrec = torch.cat(out)\n"
+        "    assert allrec.shape == (6, 26), allrec.shape\n"
+        "    assert allrec[:, 2 + 16].tolist() == [0, 1, 2, 3, 4, 5]\n"
+        "    assert allrec[:, 0].tolist() == [2.0] * 6\n"
+        "    print('GATHER_OK')\n"
+        "else:\n"
+        "    assert out is None\n")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_base_model_alias():
+    assert issubclass(superpoint_open.SuperPoint, base_model.BaseModel)
+    assert superpoint_open.__main_model__ is superpoint_open.SuperPoint
+    assert lightglue.__main_model__ is lightglue.LightGlue and not issubclass(lightglue.LightGlue, base_model.BaseModel)
