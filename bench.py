@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Benchmark of the SuperPoint + LightGlue hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Metric (BASELINE.json): image-pairs/sec, SuperPoint + LightGlue, 1024 keypoints, 640x480.
+One "step" = one pass of the hot path over one batch of synthetic pairs resident in HBM:
+extractor(view0), extractor(view1), matcher -- the sequence of TwoViewPipeline._forward
+(reference gluefactory/models/two_view_pipeline.py:278-339) without its per-call device syncs.
+Every rank processes its own `--pairs` image pairs per step (weak scaling, no data-path
+collective); one RCCL gather of per-pair records closes the job.
+
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: the pooled fp32-MFMA 3x3
+convolution, timed live with HIP events around each launch inside the timed region) and
+`cpu_baseline` (the CPU oracle, a PyTorch-CPU port of the reference path, on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from glue_factory_colon_amd import _native as nat  # noqa: E402
+from glue_factory_colon_amd import lightglue, sharding, superpoint_open, synthetic, weights  # noqa: E402
+
+METRIC = "image-pairs/sec (SuperPoint+LightGlue, 1024 kpts, 640x480)"
+H, W, K = 480, 640, 1024
+# algorithmic FLOPs (2*MAC) of the pooled 3x3 convs per image: conv1b 64->64 @480x640, conv2b 64->64 @240x320,
+# conv3b 128->128 @120x160  (22.65 + 5.66 + 5.66 GFLOP)
+POOL_CONV_FLOPS_PER_IMAGE = 2 * 9 * (64 * 64 * 480 * 640 + 64 * 64 * 240 * 320 + 128 * 128 * 120 * 160)
+PAIR_FLOPS = 182.3e9  # whole path per pair at this configuration
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(n_pairs: int, iters: int):
+    """The oracle (PyTorch-CPU port of the reference path) on the same kind of input, host cores."""
+    from oracle import lightglue as olg
+    from oracle import superpoint as osp
+
+    v0, v1 = synthetic.synthetic_pairs(n_pairs, H, W, seed=1234)
+    sd_sp, sd_lg = weights.superpoint_open_state_dict(0), weights.lightglue_state_dict(0)
+    size = torch.tensor([[float(W), float(H)]] * n_pairs)
+
+    def run():
+        a = osp.extract(sd_sp, v0, "open", nms_radius=3, max_num_keypoints=K, detection_threshold=0.0)
+        b = osp.extract(sd_sp, v1, "open", nms_radius=3, max_num_keypoints=K, detection_threshold=0.0)
+        out = olg.match(sd_lg, torch.stack(a["keypoints"]), torch.stack(b["keypoints"]),
+                        torch.stack(a["descriptors"]), torch.stack(b["descriptors"]), size, size,
+                        filter_threshold=0.1)
+        return int((out["matches0"] >= 0).sum())
+
+    run()  # warm-up
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        run()
+    dt = time.perf_counter() - t0
+    return {"value": round(n_pairs * iters / dt, 4), "unit": "image-pairs/sec", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{iters} iterations of {n_pairs} VGA pairs, 1024 kpts, oracle (PyTorch-CPU fp32 port of the "
+                      f"reference path), host has {os.cpu_count()} logical CPUs, {dt:.1f} s timed"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    args = ap.parse_args()
+
+    rank, world, local = sharding.init_from_env("nccl")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    nat.lib()  # fail loudly if the HIP library is missing
+
+    ext = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K, "detection_threshold": 0.0,
+                                      "nms_radius": 3, "force_num_keypoints": True}).eval().to(dev)
+    mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
+                               "width_confidence": -1}).eval().to(dev)
+    b = args.pairs
+    v0, v1 = synthetic.synthetic_pairs(b, H, W, seed=1234 + rank, device=dev)  # resident in HBM
+    size = torch.tensor([[float(W), float(H)]] * b, device=dev)
+    view0, view1 = {"image": v0, "image_size": size}, {"image": v1, "image_size": size}
+
+    def step():
+        p0, p1 = ext(view0), ext(view1)
+        return p0, p1, mat({"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"],
+                            "descriptors0": p0["descriptors"], "descriptors1": p1["descriptors"],
+                            "view0": view0, "view1": view1})
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        trace = nat.KernelTrace(6 * args.steps)
+        ext._runner.trace = trace
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            p0, p1, pred = step()
+        torch.cuda.synchronize(dev)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ext._runner.trace = None
+
+    # max over ranks
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # the one collective of the path: gather of fixed-size per-pair records to rank 0
+    rec = sharding.pack_pair_records({**pred, "keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"]}, K)
+    tg = time.perf_counter()
+    gathered = sharding.gather_records(rec)
+    torch.cuda.synchronize(dev)
+    gather_ms = (time.perf_counter() - tg) * 1e3
+
+    durs = trace.durations_ms()
+    trace.close()
+    if rank == 0:
+        allrec = torch.cat(gathered)
+        n_pairs_total = allrec.shape[0]
+        mean_matches = float(allrec[:, 0].mean())
+        avg_ms = sum(durs) / max(len(durs), 1)
+        flops_per_launch = POOL_CONV_FLOPS_PER_IMAGE * b / 3.0  # 3 launches of this kernel per extractor call
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if durs else 0.0
+        value = world * b * args.steps / elapsed
+        out = {
+            "metric": METRIC,
+            "value": round(value, 3),
+            "unit": "image-pairs/sec",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "SuperPoint-open + LightGlue, 1024 kpts, 640x480 synthetic pairs "
+                                   "(BASELINE.json configs[1])", "pairs_per_gpu_per_step": b,
+                       "global_pairs_per_step": b * world, "keypoints": K, "image": [H, W],
+                       "parallelism": f"dp{world} (pairs sharded, one final gather)",
+                       "weights": "name-seeded seed 0 (no network)", "mean_matches_per_pair": round(mean_matches, 1),
+                       "pairs_gathered": n_pairs_total, "final_gather_ms": round(gather_ms, 3),
+                       "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true> (3x3 conv + ReLU + BN + 2x2 max-pool)",
+                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),
+                         "flops_per_launch": flops_per_launch},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,6 +28,10 @@ class SpParams(Structure):
                 ("desc_dim", c_int)]
 
 
+class Trace(Structure):
+    _fields_ = [("start", POINTER(c_void_p)), ("stop", POINTER(c_void_p)), ("capacity", c_int), ("count", c_int)]
+
+
 _LG_ARRAYS = ["wqkv", "bqkv", "s_out_w", "s_out_b", "s_ffn0_w", "s_ffn0_b", "s_ln_g", "s_ln_b", "s_ffn3_w",
               "s_ffn3_b", "c_qkv_w", "c_qkv_b", "c_out_w", "c_out_b", "c_ffn0_w", "c_ffn0_b", "c_ln_g", "c_ln_b",
               "c_ffn3_w", "c_ffn3_b"]
@@ -58,7 +62,10 @@ SIGNATURES = {
     "gfc_layernorm_gelu": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfc_sp_workspace_bytes": (c_size_t, [c_int] * 4),
     "gfc_sp_dense": (c_int, [POINTER(SpParams), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                             c_size_t, c_void_p]),
+                             c_size_t, POINTER(Trace), c_void_p]),
+    "gfc_event_create": (c_int, [POINTER(c_void_p)]),
+    "gfc_event_destroy": (c_int, [c_void_p]),
+    "gfc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "gfc_sp_nms": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfc_sp_select_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_sp_select": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -128,3 +135,42 @@ class Workspace:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != device:
             self.buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
         return self.buf
+
+
+class KernelTrace:
+    """Host-side owner of a gfc_trace: `capacity` hipEvent pairs recorded by the library around
+    the launches of the dominant kernel (see include/gfc_amd.h)."""
+
+    def __init__(self, capacity: int):
+        l = lib()
+        self.capacity = capacity
+        self.starts = (c_void_p * capacity)()
+        self.stops = (c_void_p * capacity)()
+        for arr in (self.starts, self.stops):
+            for i in range(capacity):
+                ev = c_void_p()
+                check(l.gfc_event_create(ctypes.byref(ev)), "gfc_event_create")
+                arr[i] = ev
+        self.c = Trace(ctypes.cast(self.starts, POINTER(c_void_p)), ctypes.cast(self.stops, POINTER(c_void_p)),
+                       capacity, 0)
+
+    def reset(self):
+        self.c.count = 0
+
+    def durations_ms(self):
+        """Call after a device synchronisation."""
+        l = lib()
+        out = []
+        for i in range(self.c.count):
+            ms = c_float()
+            check(l.gfc_event_elapsed_ms(self.starts[i], self.stops[i], ctypes.byref(ms)), "gfc_event_elapsed_ms")
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        l = lib()
+        for arr in (self.starts, self.stops):
+            for i in range(self.capacity):
+                if arr[i]:
+                    l.gfc_event_destroy(arr[i])
+                    arr[i] = None

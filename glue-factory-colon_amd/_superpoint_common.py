@@ -90,8 +90,8 @@ def pad_random_c(kpts, scores, counts, k, low, high):
     mn = torch.where(valid, kpts, kpts.new_full((), big)).amin(1, keepdim=True)
     mx = torch.where(valid, kpts, kpts.new_full((), -big)).amax(1, keepdim=True)
     empty = (counts == 0)[:, None, None]
-    mn = torch.where(empty, kpts.new_full((), float(low)), mn)
-    mx = torch.where(empty, kpts.new_full((), float(high)), mx)
+    mn = torch.where(empty, torch.as_tensor(low, device=kpts.device, dtype=kpts.dtype), mn)
+    mx = torch.where(empty, torch.as_tensor(high, device=kpts.device, dtype=kpts.dtype), mx)
     fill = torch.rand((b, cap, 2), device=kpts.device, dtype=kpts.dtype) * (mx - mn) + mn
     kpts = torch.where(valid, kpts, fill)
     scores = torch.where(valid[..., 0], scores, scores.new_zeros(()))
@@ -104,6 +104,7 @@ class SuperPointRunner:
     def __init__(self):
         self.ws = nat.Workspace()
         self.ws_sel = nat.Workspace()
+        self.trace = None  # optional nat.KernelTrace (bench.py): per-launch events of the dominant kernel
 
     def dense(self, packed, image):
         lib = nat.lib()
@@ -115,7 +116,9 @@ class SuperPointRunner:
         need = lib.gfc_sp_workspace_bytes(b, c, h, w)
         ws = self.ws.get(need, dev)
         nat.check(lib.gfc_sp_dense(ctypes.byref(packed.params), nat.ptr(image), b, c, h, w, nat.ptr(heat),
-                                   nat.ptr(desc), nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "gfc_sp_dense")
+                                   nat.ptr(desc), nat.ptr(ws), ws.numel(),
+                                   ctypes.byref(self.trace.c) if self.trace is not None else None,
+                                   nat.stream_ptr(dev)), "gfc_sp_dense")
         return heat, desc
 
     def nms(self, heat, radius, border, valid_wh=None):
@@ -181,7 +184,8 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
     if force_num_keypoints:
         if k is None:
             raise ValueError("force_num_keypoints needs max_num_keypoints")
-        bound = data["image_size"].min().item() if "image_size" in data else min(image.shape[-2:])
+        # kept on the device: no host synchronisation on the batched path
+        bound = data["image_size"].min() if "image_size" in data else min(image.shape[-2:])
         kpts, ksc = pad_random_c(kpts, ksc, counts, k, 0, bound)
         counts_arg = None
     else:

@@ -49,8 +49,37 @@ extern "C" size_t gfc_sp_workspace_bytes(int B, int C, int H, int W) {
   return p.gray + p.bufA + p.bufB;
 }
 
+extern "C" int gfc_event_create(void** event) {
+  if (!event) return GFC_ERR_INVALID;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return GFC_ERR_LAUNCH;
+  *event = (void*)e;
+  return GFC_OK;
+}
+extern "C" int gfc_event_destroy(void* event) {
+  return hipEventDestroy((hipEvent_t)event) == hipSuccess ? GFC_OK : GFC_ERR_LAUNCH;
+}
+extern "C" int gfc_event_elapsed_ms(void* start, void* stop, float* ms) {
+  if (!start || !stop || !ms) return GFC_ERR_INVALID;
+  return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? GFC_OK : GFC_ERR_LAUNCH;
+}
+
+// pooled conv with optional event bracket (the dominant kernel of the path)
+static int traced_pool_conv(gfc_trace* tr, hipStream_t st, const float* x, const float* w, const float* bias,
+                            const float* scale, const float* shift, float* y, int B, int H, int W, int cin, int cout) {
+  const bool rec = tr && tr->start && tr->stop && tr->count < tr->capacity;
+  if (rec && hipEventRecord((hipEvent_t)tr->start[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
+  int s = gfc_conv3x3(x, w, bias, scale, shift, y, B, H, W, cin, cout, 1, 1, st);
+  if (s != GFC_OK) return s;
+  if (rec) {
+    if (hipEventRecord((hipEvent_t)tr->stop[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
+    tr->count++;
+  }
+  return GFC_OK;
+}
+
 extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, int C, int H, int W, float* heatmap,
-                            float* desc_raw, void* ws, size_t ws_bytes, void* stream) {
+                            float* desc_raw, void* ws, size_t ws_bytes, gfc_trace* trace, void* stream) {
   if (!p || !image || !heatmap || !desc_raw || !ws || B <= 0 || (C != 1 && C != 3) || H < 8 || W < 8)
     return GFC_ERR_INVALID;
   if (p->desc_dim <= 0) return GFC_ERR_INVALID;
@@ -70,13 +99,13 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   const int* Ws = pl.W;
   // conv1a, conv1b+pool
   GFC_TRY(gfc_conv3x3(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], A, B, Hs[1], Ws[1], 1, 64, 1, 0, st));
-  GFC_TRY(gfc_conv3x3(A, p->w[1], p->bias[1], p->scale[1], p->shift[1], Bf, B, Hs[1], Ws[1], 64, 64, 1, 1, st));
+  GFC_TRY(traced_pool_conv(trace, st, A, p->w[1], p->bias[1], p->scale[1], p->shift[1], Bf, B, Hs[1], Ws[1], 64, 64));
   // conv2a, conv2b+pool
   GFC_TRY(gfc_conv3x3(Bf, p->w[2], p->bias[2], p->scale[2], p->shift[2], A, B, Hs[2], Ws[2], 64, 64, 1, 0, st));
-  GFC_TRY(gfc_conv3x3(A, p->w[3], p->bias[3], p->scale[3], p->shift[3], Bf, B, Hs[2], Ws[2], 64, 64, 1, 1, st));
+  GFC_TRY(traced_pool_conv(trace, st, A, p->w[3], p->bias[3], p->scale[3], p->shift[3], Bf, B, Hs[2], Ws[2], 64, 64));
   // conv3a, conv3b+pool
   GFC_TRY(gfc_conv3x3(Bf, p->w[4], p->bias[4], p->scale[4], p->shift[4], A, B, Hs[3], Ws[3], 64, 128, 1, 0, st));
-  GFC_TRY(gfc_conv3x3(A, p->w[5], p->bias[5], p->scale[5], p->shift[5], Bf, B, Hs[3], Ws[3], 128, 128, 1, 1, st));
+  GFC_TRY(traced_pool_conv(trace, st, A, p->w[5], p->bias[5], p->scale[5], p->shift[5], Bf, B, Hs[3], Ws[3], 128, 128));
   // conv4a, conv4b
   GFC_TRY(gfc_conv3x3(Bf, p->w[6], p->bias[6], p->scale[6], p->shift[6], A, B, Hs[4], Ws[4], 128, 128, 1, 0, st));
   GFC_TRY(gfc_conv3x3(A, p->w[7], p->bias[7], p->scale[7], p->shift[7], Bf, B, Hs[4], Ws[4], 128, 128, 1, 0, st));

@@ -124,13 +124,30 @@ typedef struct {
 
 typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;
 
+/* Optional per-launch timing of the dominant kernel (host struct owned by the caller, no global
+ * state): gfc_sp_dense brackets every launch of the pooled 3x3 MFMA convolution
+ * (conv1b / conv2b / conv3b) with hipEventRecord(start[count]) / hipEventRecord(stop[count]) on the
+ * call's stream and increments count (while count < capacity).  Events come from
+ * gfc_event_create().  Used by bench.py for the live roofline figure; NULL in production. */
+typedef struct {
+  void** start;
+  void** stop;
+  int capacity;
+  int count;
+} gfc_trace;
+
+int gfc_event_create(void** event);
+int gfc_event_destroy(void* event);
+/* milliseconds between two recorded events (both must have completed) */
+int gfc_event_elapsed_ms(void* start, void* stop, float* ms);
+
 size_t gfc_sp_workspace_bytes(int B, int C, int H, int W);
 
 /* image [B,C,H,W] (C = 1 or 3, RGB -> grey fused) -> heat-map [B, 8*(H/8), 8*(W/8)] (softmax over
  * 65 logits, dustbin dropped, depth-to-space) and raw descriptor map [B,H/8,W/8,desc_dim]
  * (NHWC, before L2 normalisation).  superpoint_open.py:128-144; superpoint.py:208-241. */
 int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, int C, int H, int W, float* heatmap,
-                 float* desc_raw, void* ws, size_t ws_bytes, void* stream);
+                 float* desc_raw, void* ws, size_t ws_bytes, gfc_trace* trace, void* stream);
 
 /* Max-pool NMS with two recovery rounds, then outer `border` rows/cols := -1.
  * valid_wh (nullable, int32 [B,2] = (w,h)): right/bottom border measured from the true image

@@ -14,6 +14,24 @@ from oracle import lightglue as olg  # noqa: E402
 from oracle import superpoint as osp  # noqa: E402
 
 DEV = "cuda"
+_KEEP = []
+
+
+def D(t):
+    """Move to the device and keep the tensor alive until the end of the test: the library gets
+    raw pointers, so a temporary `.to(DEV)` would be freed (and its block reused) too early."""
+    if t is None:
+        return None
+    t = t.to(DEV).contiguous()
+    _KEEP.append(t)
+    return t
+
+
+@pytest.fixture(autouse=True)
+def _release_kept():
+    yield
+    torch.cuda.synchronize()
+    _KEEP.clear()
 
 
 def st():
@@ -57,8 +75,8 @@ def test_conv3x3(cin, cout, h, w, pool, bn):
     assert torch.equal(wp.cpu(), wt.permute(2, 3, 0, 1).reshape(9, cout, cin))
     ho, wo = (h // 2, w // 2) if pool else (h, w)
     y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
-    nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(bias.to(DEV)),
-                              nat.ptr(scale_neg.to(DEV)) if bn else None, nat.ptr(shift.to(DEV)) if bn else None,
+    nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(D(bias)),
+                              nat.ptr(D(scale_neg)) if bn else None, nat.ptr(D(shift)) if bn else None,
                               nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()), "conv")
     torch.cuda.synchronize()
     assert maxerr(y.permute(0, 3, 1, 2), ref) < 2e-5
@@ -78,7 +96,7 @@ def run_linear(a0, w, bias=None, a1=None, scale=None, shift=None, alpha=1.0, res
     m, n = a0.shape[0], w.shape[0]
     ldy = ldy or n
     y = torch.full((m, ldy), float("nan"), device=DEV)
-    d = lambda t: None if t is None else t.to(DEV).contiguous()  # noqa: E731
+    d = D
     a0d, a1d, wd, bd, scd, shd, rd, cd, sd = map(d, (a0, a1, w, bias, scale, shift, residual, cos, sin))
     if rd is not None:
         y[:, :n] = rd
@@ -195,7 +213,7 @@ def test_attention_peaky_rows():
     k[3] = q[9] * 6    # early spike for query 9
     o = torch.empty((n, 256), device=DEV)
     pt = torch.tensor([[0, n, 0, n]], dtype=torch.int32, device=DEV)
-    nat.check(lib.gfc_attention(nat.ptr(q.to(DEV)), 256, nat.ptr(k.to(DEV)), 256, nat.ptr(v.to(DEV)), 256, nat.ptr(o),
+    nat.check(lib.gfc_attention(nat.ptr(D(q)), 256, nat.ptr(D(k)), 256, nat.ptr(D(v)), 256, nat.ptr(o),
                                 256, nat.ptr(pt), 1, n, 4, 0.125, st()), "attention")
     qq, kk, vv = (t.double().view(n, 4, 64).transpose(0, 1) for t in (q, k, v))
     ref = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(n, 256)
@@ -208,7 +226,7 @@ def test_layernorm_gelu():
     x = torch.randn((301, 512), generator=g) * 3 + 0.5
     gamma, beta = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g)
     xd = x.to(DEV)
-    nat.check(lib.gfc_layernorm_gelu(nat.ptr(xd), 512, 301, 512, nat.ptr(gamma.to(DEV)), nat.ptr(beta.to(DEV)), st()),
+    nat.check(lib.gfc_layernorm_gelu(nat.ptr(xd), 512, 301, 512, nat.ptr(D(gamma)), nat.ptr(D(beta)), st()),
               "ln")
     ref = F.gelu(F.layer_norm(x, (512,), gamma, beta, 1e-5))
     assert maxerr(xd, ref) < 2e-5
@@ -293,7 +311,7 @@ def test_sample_descriptors(mode, name):
     raw = dense.permute(0, 2, 3, 1).contiguous().to(DEV)
     out = torch.empty((b, n, 256), device=DEV)
     kout = torch.empty((b, n, 2), device=DEV)
-    nat.check(lib.gfc_sp_sample(nat.ptr(raw), b, h8, w8, 256, nat.ptr(kp.to(DEV)), None, n, mode, nat.ptr(out),
+    nat.check(lib.gfc_sp_sample(nat.ptr(raw), b, h8, w8, 256, nat.ptr(D(kp)), None, n, mode, nat.ptr(out),
                                 nat.ptr(kout), st()), "sample")
     assert maxerr(out, ref) < 1e-5
     assert torch.equal(kout.cpu(), kp + 0.5)
@@ -307,8 +325,8 @@ def test_log_assignment_and_filter_golden(golden):
     b, m, n = sim.shape
     out = torch.empty((b, m + 1, n + 1), device=DEV)
     ws = torch.empty(2 * b * (m + n) * 4, dtype=torch.uint8, device=DEV)
-    nat.check(lib.gfc_lg_log_assignment(nat.ptr(sim.to(DEV)), nat.ptr(z0.reshape(b, m).contiguous().to(DEV)),
-                                        nat.ptr(z1.reshape(b, n).contiguous().to(DEV)), b, m, n, nat.ptr(out),
+    nat.check(lib.gfc_lg_log_assignment(nat.ptr(D(sim)), nat.ptr(D(z0.reshape(b, m).contiguous())),
+                                        nat.ptr(D(z1.reshape(b, n).contiguous())), b, m, n, nat.ptr(out),
                                         nat.ptr(ws), ws.numel(), st()), "log_assignment")
     assert maxerr(out, gd["log_assignment"]) < 1e-5
     for th, tag in ((0.0, "0p0"), (0.1, "0p1"), (0.5, "0p5")):
@@ -326,7 +344,7 @@ def run_filter(scores, th):
     m1 = torch.empty((b, n), dtype=torch.long, device=DEV)
     s0, s1 = torch.empty((b, m), device=DEV), torch.empty((b, n), device=DEV)
     ws = torch.empty(b * (m + n) * 8, dtype=torch.uint8, device=DEV)
-    nat.check(lib.gfc_lg_filter_matches(nat.ptr(scores.to(DEV).contiguous()), b, m, n, th, nat.ptr(m0), nat.ptr(m1),
+    nat.check(lib.gfc_lg_filter_matches(nat.ptr(D(scores)), b, m, n, th, nat.ptr(m0), nat.ptr(m1),
                                         nat.ptr(s0), nat.ptr(s1), nat.ptr(ws), ws.numel(), st()), "filter")
     torch.cuda.synchronize()
     return m0.cpu(), m1.cpu(), s0.cpu(), s1.cpu()
@@ -354,8 +372,8 @@ def test_posenc(golden):
     sin = torch.empty((b * n, 64), device=DEV)
     row0 = torch.arange(b, dtype=torch.int32, device=DEV) * n
     cnt = torch.full((b,), n, dtype=torch.int32, device=DEV)
-    nat.check(lib.gfc_lg_posenc(nat.ptr(kp.reshape(-1, 2).contiguous().to(DEV)), nat.ptr(gd["image_size"].to(DEV)),
-                                nat.ptr(row0), nat.ptr(cnt), b, n, nat.ptr(wr.to(DEV).contiguous()), nat.ptr(cos),
+    nat.check(lib.gfc_lg_posenc(nat.ptr(D(kp.reshape(-1, 2).contiguous())), nat.ptr(D(gd["image_size"])),
+                                nat.ptr(row0), nat.ptr(cnt), b, n, nat.ptr(D(wr)), nat.ptr(cos),
                                 nat.ptr(sin), st()), "posenc")
     enc = gd["enc0"]  # [2,B,1,N,64]
     assert maxerr(cos.view(b, n, 64), enc[0, :, 0]) < 1e-5
