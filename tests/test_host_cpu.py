@@ -195,3 +195,33 @@ def test_base_model_alias():
     assert issubclass(superpoint_open.SuperPoint, base_model.BaseModel)
     assert superpoint_open.__main_model__ is superpoint_open.SuperPoint
     assert lightglue.__main_model__ is lightglue.LightGlue and not issubclass(lightglue.LightGlue, base_model.BaseModel)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/gluefactory"), reason="reference checkout not present")
+def test_dropin_inside_reference_registry():
+    """Build container only: the REFERENCE's get_model / TwoViewPipeline resolve and construct this package's
+    modules from a config block (subclassing the reference's own BaseModel), and report initialised."""
+    code = (
+        "import sys\n"
+        f"sys.path[:0] = [{os.path.join(ROOT, 'tests', 'golden', '_standins')!r}, '/root/reference', {ROOT!r}]\n"
+        "sys.dont_write_bytecode = True\n"
+        "from gluefactory.models import get_model\n"
+        "from gluefactory.models.base_model import BaseModel\n"
+        "from gluefactory.models.two_view_pipeline import TwoViewPipeline\n"
+        "import glue_factory_colon_amd.base_model as bm\n"
+        "assert bm.USING_REFERENCE_BASE and bm.BaseModel is BaseModel\n"
+        "ext = get_model('glue_factory_colon_amd.superpoint_open')\n"
+        "mat = get_model('glue_factory_colon_amd.lightglue')\n"
+        "assert issubclass(ext, BaseModel) and mat.__name__ == 'LightGlue'\n"
+        "assert get_model('glue_factory_colon_amd.superpoint').__module__ == 'glue_factory_colon_amd.superpoint'\n"
+        "assert issubclass(get_model('glue_factory_colon_amd.lightglue_pretrained'), BaseModel)\n"
+        "pipe = TwoViewPipeline({'extractor': {'name': 'glue_factory_colon_amd.superpoint_open', 'weights': 'synthetic',\n"
+        "    'max_num_keypoints': 1024, 'detection_threshold': 0.0, 'nms_radius': 3},\n"
+        "    'matcher': {'name': 'glue_factory_colon_amd.lightglue_pretrained', 'features': 'superpoint',\n"
+        "    'weights': 'synthetic', 'filter_threshold': 0.1}}).eval()\n"
+        "assert pipe.extractor.conf.max_num_keypoints == 1024 and pipe.extractor.conf.remove_borders == 4\n"
+        "assert pipe.is_initialized()\n"
+        "print('DROPIN_OK')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
+                       env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    assert r.returncode == 0 and "DROPIN_OK" in r.stdout, r.stdout + r.stderr
