@@ -236,9 +236,15 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
     GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, nullptr, 1.f, nullptr, cosb, sinb,
                        512, qkv, 768, R, 768, st));
     GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, 2 * B, maxn, 4, 0.125f, st));
-    GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->s_out_w[l], D, p->s_out_b[l], nullptr, nullptr, 1.f, nullptr,
-                       nullptr, nullptr, 0, msg, D, R, D, st));
-    GFC_TRY(gfc_linear(x, D, D, msg, D, D, p->s_ffn0_w[l], 512, p->s_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
+    // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
+    // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
+    const float* a1s = ctx;
+    if (p->s_out_w[l]) {
+      GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->s_out_w[l], D, p->s_out_b[l], nullptr, nullptr, 1.f, nullptr,
+                         nullptr, nullptr, 0, msg, D, R, D, st));
+      a1s = msg;
+    }
+    GFC_TRY(gfc_linear(x, D, D, a1s, D, D, p->s_ffn0_w[l], 512, p->s_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
                        nullptr, nullptr, 0, hbuf, 512, R, 512, st));
     GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->s_ln_g[l], p->s_ln_b[l], st));
     GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], nullptr, nullptr, 1.f, x,
@@ -247,9 +253,13 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
     GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, 1.f, nullptr, nullptr,
                        nullptr, 0, qkv, 512, R, 512, st));
     GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, 2 * B, maxn, 4, 0.125f, st));
-    GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,
-                       nullptr, nullptr, 0, msg, D, R, D, st));
-    GFC_TRY(gfc_linear(x, D, D, msg, D, D, p->c_ffn0_w[l], 512, p->c_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
+    const float* a1c = ctx;
+    if (p->c_out_w[l]) {
+      GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,
+                         nullptr, nullptr, 0, msg, D, R, D, st));
+      a1c = msg;
+    }
+    GFC_TRY(gfc_linear(x, D, D, a1c, D, D, p->c_ffn0_w[l], 512, p->c_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
                        nullptr, nullptr, 0, hbuf, 512, R, 512, st));
     GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->c_ln_g[l], p->c_ln_b[l], st));
     GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], nullptr, nullptr, 1.f, x,

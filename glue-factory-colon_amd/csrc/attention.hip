@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
                                                            const float* __restrict__ V, int ldv,
                                                            float* __restrict__ O, int ldo,
                                                            const int4* __restrict__ problems, float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) float Ks[AK * AKLD];
-  __shared__ __attribute__((aligned(16))) float Vs[AK * AD];
+  // double-buffered K / V tiles: [2][AK*AKLD] keys, then [2][AK*AD] values (67.6 KB -> 2 workgroups / CU)
+  __shared__ __attribute__((aligned(16))) float smem[2 * AK * AKLD + 2 * AK * AD];
 
   const int4 pb = problems[blockIdx.z];
   const int q_row0 = pb.x, nq = pb.y, kv_row0 = pb.z, nk = pb.w;
@@ -53,20 +53,48 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
   float m_run = -INFINITY, l_run = 0.f;
 
   const int ntiles = (nk + AK - 1) / AK;
+  // staging: thread -> (key = tid>>4 (+16 i), 4 floats at c4); the next tile is prefetched into
+  // registers while the current one is multiplied, then written to the other LDS buffer
+  const int st_key = tid >> 4, st_c4 = (tid & 15) * 4;
+  const float* kbase = Kp + head * AD + st_c4;
+  const float* vbase = V + head * AD + st_c4;
+  float4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
+#define ATT_LOAD(kt_)                                                                     \
+  do {                                                                                    \
+    const int kb_ = (kt_) * AK + st_key;                                                  \
+    const size_t r0_ = kv_row0 + min(kb_, nk - 1), r1_ = kv_row0 + min(kb_ + 16, nk - 1); \
+    const size_t r2_ = kv_row0 + min(kb_ + 32, nk - 1), r3_ = kv_row0 + min(kb_ + 48, nk - 1); \
+    kr0 = *reinterpret_cast<const float4*>(kbase + r0_ * ldk);                            \
+    kr1 = *reinterpret_cast<const float4*>(kbase + r1_ * ldk);                            \
+    kr2 = *reinterpret_cast<const float4*>(kbase + r2_ * ldk);                            \
+    kr3 = *reinterpret_cast<const float4*>(kbase + r3_ * ldk);                            \
+    vr0 = *reinterpret_cast<const float4*>(vbase + r0_ * ldv);                            \
+    vr1 = *reinterpret_cast<const float4*>(vbase + r1_ * ldv);                            \
+    vr2 = *reinterpret_cast<const float4*>(vbase + r2_ * ldv);                            \
+    vr3 = *reinterpret_cast<const float4*>(vbase + r3_ * ldv);                            \
+  } while (0)
+#define ATT_STORE(buf_)                                                                   \
+  do {                                                                                    \
+    float* kd_ = smem + (buf_) * AK * AKLD + st_key * AKLD + st_c4;                       \
+    float* vd_ = smem + 2 * AK * AKLD + (buf_) * AK * AD + st_key * AD + st_c4;           \
+    *reinterpret_cast<float4*>(kd_) = kr0;                                                \
+    *reinterpret_cast<float4*>(kd_ + 16 * AKLD) = kr1;                                    \
+    *reinterpret_cast<float4*>(kd_ + 32 * AKLD) = kr2;                                    \
+    *reinterpret_cast<float4*>(kd_ + 48 * AKLD) = kr3;                                    \
+    *reinterpret_cast<float4*>(vd_) = vr0;                                                \
+    *reinterpret_cast<float4*>(vd_ + 16 * AD) = vr1;                                      \
+    *reinterpret_cast<float4*>(vd_ + 32 * AD) = vr2;                                      \
+    *reinterpret_cast<float4*>(vd_ + 48 * AD) = vr3;                                      \
+  } while (0)
+
+  ATT_LOAD(0);
+  ATT_STORE(0);
+  __syncthreads();
   for (int kt = 0; kt < ntiles; ++kt) {
-    // ---- stage K and V tiles (clamped rows; masked below) ----
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int idx = tid + 256 * i;
-      int key = idx >> 4, c4 = idx & 15;
-      int kr = kv_row0 + min(kt * AK + key, nk - 1);
-      float4 kv = *reinterpret_cast<const float4*>(Kp + (size_t)kr * ldk + head * AD + c4 * 4);
-      float4 vv = *reinterpret_cast<const float4*>(V + (size_t)kr * ldv + head * AD + c4 * 4);
-      *reinterpret_cast<float4*>(Ks + key * AKLD + c4 * 4) = kv;
-      *reinterpret_cast<float4*>(Vs + key * AD + c4 * 4) = vv;
-    }
-    __syncthreads();
+    const bool has_next = kt + 1 < ntiles;
+    if (has_next) ATT_LOAD(kt + 1);
+    const float* Ks = smem + (kt & 1) * AK * AKLD;
+    const float* Vs = smem + 2 * AK * AKLD + (kt & 1) * AK * AD;
 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -95,11 +123,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f((m_run - m_new) * scale_log2e);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * scale_log2e);
       float rs = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        s[r] = exp2f((s[r] - m_new) * scale_log2e);
+        s[r] = __builtin_amdgcn_exp2f((s[r] - m_new) * scale_log2e);  // raw v_exp_f32
         rs += s[r];
       }
       rs += __shfl_xor(rs, 32);
@@ -118,6 +146,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         o[1] = mfma32(v1, s[r], o[1]);
       }
     }
+    if (has_next) ATT_STORE((kt + 1) & 1);
+    __syncthreads();
   }
 
   // ---- normalise and store: lane holds O[q][db*32 + 8*(r>>2) + 4h + (r&3)] ----

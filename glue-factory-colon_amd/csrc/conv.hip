@@ -220,29 +220,55 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   }
 
   // ---- epilogue: bias, ReLU, per-channel affine (BN), optional 2x2 max-pool ----
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int co = nb * CNB + nt * 32 + l31;
-    const float bi = a.bias[co];
-    const float sc = a.scale ? a.scale[co] : 1.f;
-    const float sh = a.shift ? a.shift[co] : 0.f;
+  if (!POOL) {
+    // Un-pooled outputs are 4x the pooled volume: transpose each 32-pixel x 64-channel block through a
+    // per-wave LDS patch (the halo tile is dead by now) and store whole float4 channel groups --
+    // 16 store instructions per wave instead of 64, each covering 4 pixels x 256 contiguous bytes.
+    constexpr int ELD = 68;
+    float* patch = in_s + wave * 32 * ELD;
+    const int er = lane >> 4, ec = (lane & 15) * 4;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-      float v[16];
+      __syncthreads();
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float t = acc[mt][nt][r] + bi;
-        if (a.relu) t = fmaxf(t, 0.f);
-        v[r] = t * sc + sh;
-      }
-      if (!POOL) {
+      for (int nt = 0; nt < 2; ++nt) {
+        const int co = nb * CNB + nt * 32 + l31;
+        const float bi = a.bias[co];
+        const float sc = a.scale ? a.scale[co] : 1.f;
+        const float sh = a.shift ? a.shift[co] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          int i = acc_row(r, h);
-          int gy = y0 + 4 * wave + 2 * mt + (i >> 4), gx = x0 + (i & 15);
-          if (gy < a.H && gx < a.W) a.y[(((size_t)b * a.H + gy) * a.W + gx) * a.cout + co] = v[r];
+          float t = acc[mt][nt][r] + bi;
+          if (a.relu) t = fmaxf(t, 0.f);
+          patch[acc_row(r, h) * ELD + nt * 32 + l31] = t * sc + sh;
         }
-      } else {
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int p = er + 4 * i;  // pixel inside the 2x16 block
+        const int gy = y0 + 4 * wave + 2 * mt + (p >> 4), gx = x0 + (p & 15);
+        const float4 v = *reinterpret_cast<const float4*>(patch + p * ELD + ec);
+        if (gy < a.H && gx < a.W)
+          *reinterpret_cast<float4*>(a.y + (((size_t)b * a.H + gy) * a.W + gx) * a.cout + nb * CNB + ec) = v;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int co = nb * CNB + nt * 32 + l31;
+      const float bi = a.bias[co];
+      const float sc = a.scale ? a.scale[co] : 1.f;
+      const float sh = a.shift ? a.shift[co] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float t = acc[mt][nt][r] + bi;
+          if (a.relu) t = fmaxf(t, 0.f);
+          v[r] = t * sc + sh;
+        }
         const int Ho = a.H >> 1, Wo = a.W >> 1;
         const int oy = (y0 >> 1) + 2 * wave + mt;
 #pragma unroll

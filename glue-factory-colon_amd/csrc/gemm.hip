@@ -5,14 +5,16 @@
 // the 1x1 convolutions of the SuperPoint heads (superpoint_open.py:112-118, NHWC makes them
 // plain GEMMs) and, in batched form, einsum("bmd,bnd->bmn") (lightglue.py:285).
 //
-// Workgroup = 4 waves = 128x128 output tile, K stepped by 32 through LDS (row stride 36 floats:
-// conflict-free ds_read_b128 of 4 consecutive k per lane).  Each wave owns a 64x64 sub-tile =
-// 2x2 MFMA 32x32 tiles; per 8-deep k group it issues 4 LDS reads and 16 v_mfma_f32_32x32x2_f32.
-// The next K tile is prefetched global->registers while the current one is multiplied.
+// Workgroup = 8 waves = 128x256 output tile (4 waves = 128x128 for narrow N), K stepped by 32 through
+// double-buffered LDS (row stride 36 floats: conflict-free ds_read_b128 of 4 consecutive k per lane).
+// Each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 tiles; per 8-deep k group it issues 4 LDS reads
+// and 16 v_mfma_f32_32x32x2_f32.  The next K tile is prefetched global->registers while the current
+// one is multiplied; one barrier per K tile.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define GBM 128
-#define GBN 128
 #define GBK 32
 #define GLD (GBK + 4)
 
@@ -33,70 +35,76 @@ struct GemmArgs {
   float alpha;
 };
 
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
-  __shared__ __attribute__((aligned(16))) float Bs[GBN * GLD];
+// NW = waves along N.  NW = 2: 128x128 tile, 256 threads, 72 KB LDS (2 workgroups / CU).
+//                      NW = 4: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup = 8 waves / CU).
+// LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
+// underneath the 64 MFMAs per wave of the current one.
+template <int NW>
+__global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
+  constexpr int T = 128 * NW;        // threads
+  constexpr int BN = 64 * NW;        // tile width
+  constexpr int RPP = T / 8;         // rows staged per pass
+  constexpr int NA = GBM / RPP;      // float4 of A per thread per K tile
+  constexpr int NB = BN / RPP;       // float4 of W per thread per K tile
+  constexpr int TILE = (GBM + BN) * GLD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int wm = wave / NW, wn = wave % NW;
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
   const long long z = blockIdx.z;
   const float* A0 = g.A0 + z * g.strideA;
   const float* A1 = g.A1 ? g.A1 + z * g.strideA : nullptr;
   const float* W = g.W + z * g.strideW;
   float* Y = g.Y + z * g.strideY;
-  const int K = g.K0 + g.K1;
-  const int ktiles = K / GBK;
+  const int ktiles = (g.K0 + g.K1) / GBK;
 
-  // global -> register staging: 4 float4 of A and 4 of W per thread per K tile
-  // (macros, not lambdas: the prefetch registers must stay in VGPRs, not in a private-memory array)
   const int s_c4 = (tid & 7) * 4;
-  const int s_r0 = tid >> 3;  // rows s_r0 + 32*i
-  const float* a_src[4];
-  const float* a1_src[4];
-  const float* w_src[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = min(m0 + s_r0 + 32 * i, g.M - 1);
-    const int n = min(n0 + s_r0 + 32 * i, g.N - 1);
-    a_src[i] = A0 + (size_t)r * g.lda0 + s_c4;
-    a1_src[i] = A1 ? A1 + (size_t)r * g.lda1 + s_c4 : nullptr;
-    w_src[i] = W + (size_t)n * g.ldw + s_c4;
-  }
+  const int s_r0 = tid >> 3;
+  // staged rows (clamped; out-of-range rows are never stored by the epilogue).  Named registers and
+  // wave-uniform pointer selection: arrays / per-branch loads were demoted to private memory by hipcc.
+  const int ar0 = min(m0 + s_r0, g.M - 1), ar1 = min(m0 + s_r0 + RPP, g.M - 1);
+  const int ar2 = min(m0 + s_r0 + 2 * RPP, g.M - 1), ar3 = min(m0 + s_r0 + 3 * RPP, g.M - 1);
+  const float* w0p = W + (size_t)min(n0 + s_r0, g.N - 1) * g.ldw + s_c4;
+  const float* w1p = W + (size_t)min(n0 + s_r0 + RPP, g.N - 1) * g.ldw + s_c4;
+  const float* w2p = W + (size_t)min(n0 + s_r0 + 2 * RPP, g.N - 1) * g.ldw + s_c4;
+  const float* w3p = W + (size_t)min(n0 + s_r0 + 3 * RPP, g.N - 1) * g.ldw + s_c4;
+  static_assert(NB == 4 && (NA == 2 || NA == 4), "staging layout");
   float4 areg0, areg1, areg2, areg3, wreg0, wreg1, wreg2, wreg3;
-#define GEMM_LOAD_TILE(kt)                                                                      \
-  do {                                                                                          \
-    const int k0_ = (kt) * GBK;                                                                 \
-    if (k0_ < g.K0) {                                                                           \
-      areg0 = *reinterpret_cast<const float4*>(a_src[0] + k0_);                                 \
-      areg1 = *reinterpret_cast<const float4*>(a_src[1] + k0_);                                 \
-      areg2 = *reinterpret_cast<const float4*>(a_src[2] + k0_);                                 \
-      areg3 = *reinterpret_cast<const float4*>(a_src[3] + k0_);                                 \
-    } else {                                                                                    \
-      areg0 = *reinterpret_cast<const float4*>(a1_src[0] + (k0_ - g.K0));                       \
-      areg1 = *reinterpret_cast<const float4*>(a1_src[1] + (k0_ - g.K0));                       \
-      areg2 = *reinterpret_cast<const float4*>(a1_src[2] + (k0_ - g.K0));                       \
-      areg3 = *reinterpret_cast<const float4*>(a1_src[3] + (k0_ - g.K0));                       \
-    }                                                                                           \
-    wreg0 = *reinterpret_cast<const float4*>(w_src[0] + k0_);                                   \
-    wreg1 = *reinterpret_cast<const float4*>(w_src[1] + k0_);                                   \
-    wreg2 = *reinterpret_cast<const float4*>(w_src[2] + k0_);                                   \
-    wreg3 = *reinterpret_cast<const float4*>(w_src[3] + k0_);                                   \
+  areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define GEMM_LOAD_TILE(kt)                                                                           \
+  do {                                                                                               \
+    const int k0_ = (kt) * GBK;                                                                      \
+    const bool first_ = k0_ < g.K0;                                                                  \
+    const float* ab_ = (first_ ? A0 : A1) + (first_ ? k0_ : k0_ - g.K0) + s_c4;                      \
+    const size_t ld_ = first_ ? g.lda0 : g.lda1;                                                     \
+    areg0 = *reinterpret_cast<const float4*>(ab_ + ar0 * ld_);                                       \
+    areg1 = *reinterpret_cast<const float4*>(ab_ + ar1 * ld_);                                       \
+    if constexpr (NA == 4) {                                                                         \
+      areg2 = *reinterpret_cast<const float4*>(ab_ + ar2 * ld_);                                     \
+      areg3 = *reinterpret_cast<const float4*>(ab_ + ar3 * ld_);                                     \
+    }                                                                                                \
+    wreg0 = *reinterpret_cast<const float4*>(w0p + k0_);                                             \
+    wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                                             \
+    wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                                             \
+    wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                                             \
   } while (0)
-#define GEMM_STORE_TILE()                                                                       \
-  do {                                                                                          \
-    float* as_ = As + s_r0 * GLD + s_c4;                                                        \
-    float* bs_ = Bs + s_r0 * GLD + s_c4;                                                        \
-    *reinterpret_cast<float4*>(as_) = areg0;                                                    \
-    *reinterpret_cast<float4*>(as_ + 32 * GLD) = areg1;                                         \
-    *reinterpret_cast<float4*>(as_ + 64 * GLD) = areg2;                                         \
-    *reinterpret_cast<float4*>(as_ + 96 * GLD) = areg3;                                         \
-    *reinterpret_cast<float4*>(bs_) = wreg0;                                                    \
-    *reinterpret_cast<float4*>(bs_ + 32 * GLD) = wreg1;                                         \
-    *reinterpret_cast<float4*>(bs_ + 64 * GLD) = wreg2;                                         \
-    *reinterpret_cast<float4*>(bs_ + 96 * GLD) = wreg3;                                         \
+#define GEMM_STORE_TILE(buf_)                                                                        \
+  do {                                                                                               \
+    float* as_ = smem + (buf_) * TILE + s_r0 * GLD + s_c4;                                           \
+    float* bs_ = as_ + GBM * GLD;                                                                    \
+    *reinterpret_cast<float4*>(as_) = areg0;                                                         \
+    *reinterpret_cast<float4*>(as_ + RPP * GLD) = areg1;                                             \
+    if constexpr (NA == 4) {                                                                         \
+      *reinterpret_cast<float4*>(as_ + 2 * RPP * GLD) = areg2;                                       \
+      *reinterpret_cast<float4*>(as_ + 3 * RPP * GLD) = areg3;                                       \
+    }                                                                                                \
+    *reinterpret_cast<float4*>(bs_) = wreg0;                                                         \
+    *reinterpret_cast<float4*>(bs_ + RPP * GLD) = wreg1;                                             \
+    *reinterpret_cast<float4*>(bs_ + 2 * RPP * GLD) = wreg2;                                         \
+    *reinterpret_cast<float4*>(bs_ + 3 * RPP * GLD) = wreg3;                                         \
   } while (0)
 
   f32x16 acc[2][2];
@@ -107,15 +115,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const float* ap = As + (wm * 64 + l31) * GLD + 4 * h;
-  const float* bp = Bs + (wn * 64 + l31) * GLD + 4 * h;
+  const int a_off = (wm * 64 + l31) * GLD + 4 * h;
+  const int b_off = GBM * GLD + (wn * 64 + l31) * GLD + 4 * h;
 
   GEMM_LOAD_TILE(0);
-  GEMM_STORE_TILE();
+  GEMM_STORE_TILE(0);
   __syncthreads();
   for (int kt = 0; kt < ktiles; ++kt) {
     const bool has_next = kt + 1 < ktiles;
     if (has_next) GEMM_LOAD_TILE(kt + 1);
+    const float* ap = smem + (kt & 1) * TILE + a_off;
+    const float* bp = smem + (kt & 1) * TILE + b_off;
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
       float4 af[2], bf[2];
@@ -133,58 +143,124 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(GemmArgs g) {
           acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
         }
     }
+    if (has_next) GEMM_STORE_TILE((kt + 1) & 1);
     __syncthreads();
-    if (has_next) {
-      GEMM_STORE_TILE();
-      __syncthreads();
-    }
   }
 
   // ---- epilogue ----
+  if (g.rot_cos == nullptr && g.residual == nullptr) {
+    // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
+    // measured faster than the LDS transpose below when nothing has to be loaded per element
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = n0 + wn * 64 + nt * 32 + l31;
-    const bool col_ok = col < g.N;
-    const int cc = col_ok ? col : g.N - 1;
-    const float bi = g.bias ? g.bias[cc] : 0.f;
-    const float sc = g.scale ? g.scale[cc] : 1.f;
-    const float sh = g.shift ? g.shift[cc] : 0.f;
-    const bool rot = g.rot_cos != nullptr && col < g.rot_cols;  // wave-uniform per 32-col tile (rot_cols % 64 == 0)
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wn * 64 + nt * 32 + l31;
+      const bool col_ok = col < g.N;
+      const int cc = col_ok ? col : g.N - 1;
+      const float bi = g.bias ? g.bias[cc] : 0.f;
+      const float sc = g.scale ? g.scale[cc] : 1.f;
+      const float sh = g.shift ? g.shift[cc] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + acc_row(r, h);
-        const bool row_ok = row < g.M;
-        float v = acc[mt][nt][r] + bi;
-        if (g.rot_cos != nullptr) {
-          // rotary: out[d] = t[d]*cos[d] + rot(t)[d]*sin[d], rot(t)[2i] = -t[2i+1], rot(t)[2i+1] = t[2i]
-          float other = __shfl_xor(v, 1);
-          if (rot) {
-            const int rr = row_ok ? row : g.M - 1;
-            const int d = col & 63;
-            float c = g.rot_cos[(size_t)rr * 64 + d], s = g.rot_sin[(size_t)rr * 64 + d];
-            float rv = (col & 1) ? other : -other;
-            v = v * c + rv * s;
-          }
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * 64 + mt * 32 + acc_row(r, h);
+          float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
+          if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
         }
-        v = v * sc + sh;
-        v *= g.alpha;
-        if (row_ok && col_ok) {
-          size_t o = (size_t)row * g.ldy + col;
-          if (g.residual) v = g.residual[o] + v;
-          Y[o] = v;
+      }
+    }
+    return;
+  }
+  // Rotary / residual epilogues load per element: in the accumulator layout that is one float per
+  // lane per instruction.  Each wave transposes its tile through its own LDS patch instead (the
+  // K-loop buffers are free now) and handles whole float4 row segments: 4x fewer loads and stores.
+  constexpr int ELD = 68;  // patch row stride (floats): 32 rows x 64 cols per round
+  float* patch = smem + wave * 32 * ELD;
+  const bool vec_ok = (g.ldy % 4 == 0) && ((reinterpret_cast<size_t>(Y) & 15) == 0) &&
+                      (!g.residual || (reinterpret_cast<size_t>(g.residual) & 15) == 0);
+  const int er = lane >> 4, ec = (lane & 15) * 4;  // this lane's row (+4 per step) and 4 columns
+  const int colb = n0 + wn * 64 + ec;
+  float4 bi4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bi4;
+  {
+    float* bp4 = reinterpret_cast<float*>(&bi4);
+    float* sp4 = reinterpret_cast<float*>(&sc4);
+    float* hp4 = reinterpret_cast<float*>(&sh4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = min(colb + j, g.N - 1);
+      if (g.bias) bp4[j] = g.bias[cc];
+      if (g.scale) { sp4[j] = g.scale[cc]; hp4[j] = g.shift[cc]; }
+    }
+  }
+  const bool rot = g.rot_cos != nullptr && colb < g.rot_cols;
+  const int rd = colb & 63;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    __syncthreads();  // previous round's reads (or the K loop's) are complete
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int lr = er + 4 * i;
+      const int row = m0 + wm * 64 + mt * 32 + lr;
+      float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
+      if (row >= g.M) continue;
+      v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
+      if (rot) {
+        // rotary: out[d] = t[d]*cos[d] + rot(t)[d]*sin[d], rot(t)[2i] = -t[2i+1], rot(t)[2i+1] = t[2i]
+        const float4 c = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row * 64 + rd);
+        const float4 sn = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row * 64 + rd);
+        const float x = v.x, y = v.y, zz = v.z, w = v.w;
+        v.x = x * c.x + (-y) * sn.x;
+        v.y = y * c.y + x * sn.y;
+        v.z = zz * c.z + (-w) * sn.z;
+        v.w = w * c.w + zz * sn.w;
+      }
+      v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+      v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+      const size_t o = (size_t)row * g.ldy + colb;
+      if (vec_ok && colb + 3 < g.N) {
+        if (g.residual) {
+          const float4 rs = *reinterpret_cast<const float4*>(g.residual + o);
+          v.x = rs.x + v.x; v.y = rs.y + v.y; v.z = rs.z + v.z; v.w = rs.w + v.w;
         }
+        *reinterpret_cast<float4*>(Y + o) = v;
+      } else {
+        const float* vp = reinterpret_cast<const float*>(&v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (colb + j < g.N) Y[o + j] = g.residual ? g.residual[o + j] + vp[j] : vp[j];
       }
     }
   }
 }
 
-static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
-  dim3 grid((g.N + GBN - 1) / GBN, (g.M + GBM - 1) / GBM, batch);
-  hipLaunchKernelGGL(gemm_nt_kernel, grid, dim3(256), 0, st, g);
+template <int NW>
+static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
+  constexpr int BN = 64 * NW;
+  const size_t lds = (size_t)2 * (GBM + BN) * GLD * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid((g.N + BN - 1) / BN, (g.M + GBM - 1) / GBM, batch);
+  hipLaunchKernelGGL(gemm_nt_kernel<NW>, grid, dim3(128 * NW), lds, st, g);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
+}
+
+static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
+  // tuning knob (tools/bench_kernels.py): GFC_GEMM_NW=2|4 forces the tile width
+  static const int forced = [] { const char* e = getenv("GFC_GEMM_NW"); return e ? atoi(e) : 0; }();
+  if (forced == 2) return launch_gemm_t<2>(g, batch, st);
+  if (forced == 4) return launch_gemm_t<4>(g, batch, st);
+  // wide tile whenever N fills it; the 128-wide variant serves narrow outputs (e.g. the 65 detector logits)
+  if (g.N % 256 == 0) return launch_gemm_t<4>(g, batch, st);
+  return launch_gemm_t<2>(g, batch, st);
 }
 
 extern "C" int gfc_linear(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W, int ldw,

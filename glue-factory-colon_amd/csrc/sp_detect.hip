@@ -55,111 +55,158 @@ int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* hea
 //   twice: near = mp(keep) > 0;  t = near ? 0 : s;  keep |= (t == mp(t)) & ~near
 //   out   = keep ? s : 0
 // mp = (2r+1)^2 max-pool, stride 1, -inf padding.  The 5 dependent pools need a 5r halo, so a
-// 32x32 output tile works on a (32+10r)^2 LDS image; every pool is separable (row max, col max).
+// 64x64 output tile works on a (64+10r)^2 LDS image; every pool is separable (row pass, column pass)
+// and the pools of the 0/1 keep mask are byte ORs.  10 LDS passes per tile, 1024 threads.
 // Float equality is evaluated on the same fp32 values the reference compares: bit-exact.
 // ------------------------------------------------------------------------------------------
-#define NT 32
+#define NT 64
 #define NR_MAX 4
-#define NRG (NT + 10 * NR_MAX)  // 72
 
-__device__ __forceinline__ void pool_rows(const float* src, float* dst, int R, int r, int tid) {
-  // horizontal running max: dst[y][x] = max_{|d|<=r} src[y][x+d]   (out of tile -> -inf)
-  for (int i = tid; i < R * R; i += 256) {
-    int y = i / R, x = i - y * R;
-    float m = -INFINITY;
-    int lo = max(x - r, 0), hi = min(x + r, R - 1);
-    for (int xx = lo; xx <= hi; ++xx) m = fmaxf(m, src[y * R + xx]);
-    dst[i] = m;
+// One separable max / OR pass over the LDS image.  Each work item owns SEG consecutive positions of
+// one line and slides the (2*RAD+1) window through registers: SEG + 2*RAD LDS reads for SEG outputs.
+// ROW passes map consecutive lanes to consecutive lines (odd line stride RS -> conflict-free);
+// COLUMN passes map consecutive lanes to consecutive columns.
+template <int RAD, int R, int RS, int SEG, int NSEG, bool ROW, typename T, typename F>
+__device__ __forceinline__ void window_pass(const T* __restrict__ src, T lowest, int tid, F&& emit) {
+  for (int item = tid; item < R * NSEG; item += 1024) {
+    const int line = item % R, seg = item / R;
+    const int p0 = seg * SEG;
+    T w[SEG + 2 * RAD];
+#pragma unroll
+    for (int j = 0; j < SEG + 2 * RAD; ++j) {
+      const int p = p0 - RAD + j;
+      const bool ok = p >= 0 && p < R;
+      const int idx = ROW ? line * RS + p : p * RS + line;
+      w[j] = ok ? src[idx] : lowest;
+    }
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+      if (p0 + j < R) {
+        T m = w[j];
+#pragma unroll
+        for (int d = 1; d <= 2 * RAD; ++d) m = (w[j + d] > m) ? w[j + d] : m;
+        emit(ROW ? line * RS + p0 + j : (p0 + j) * RS + line, m);
+      }
+    }
   }
 }
-__device__ __forceinline__ void pool_cols(const float* src, float* dst, int R, int r, int tid) {
-  for (int i = tid; i < R * R; i += 256) {
-    int y = i / R, x = i - y * R;
-    float m = -INFINITY;
-    int lo = max(y - r, 0), hi = min(y + r, R - 1);
-    for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, src[yy * R + x]);
-    dst[i] = m;
-  }
-}
 
-__global__ __launch_bounds__(256) void nms_kernel(const float* __restrict__ heat, int H, int W, int r, int border,
-                                                  const int* __restrict__ valid_wh, float* __restrict__ out) {
-  __shared__ float s[NRG * NRG];   // scores (-inf outside the image)
-  __shared__ float t0[NRG * NRG];  // scratch
-  __shared__ float t1[NRG * NRG];  // scratch
-  __shared__ unsigned char keep[NRG * NRG];
+template <int RAD>
+__global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ heat, int H, int W, int border,
+                                                   const int* __restrict__ valid_wh, float* __restrict__ out) {
+  constexpr int HALO = 5 * RAD;
+  constexpr int R = NT + 2 * HALO;
+  constexpr int RS = R | 1;
+  constexpr int NSEG = 1024 / R;
+  constexpr int SEG = (R + NSEG - 1) / NSEG;
+  extern __shared__ __attribute__((aligned(16))) float nsm[];
+  float* s = nsm;            // scores, -inf outside the image
+  float* t0 = s + R * RS;
+  float* t1 = t0 + R * RS;
+  unsigned char* keep = reinterpret_cast<unsigned char*>(t1 + R * RS);  // bit0 keep, bit1 near
+  unsigned char* tb = keep + R * RS;
+
   const int tid = threadIdx.x;
   const int tiles_x = (W + NT - 1) / NT;
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
-  const int halo = 5 * r, R = NT + 2 * halo;
-  const int gx0 = tx * NT - halo, gy0 = ty * NT - halo;
+  const int gx0 = tx * NT - HALO, gy0 = ty * NT - HALO;
   const float* hb = heat + (size_t)b * H * W;
-  for (int i = tid; i < R * R; i += 256) {
-    int y = i / R, x = i - y * R;
-    int gy = gy0 + y, gx = gx0 + x;
-    s[i] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hb[(size_t)gy * W + gx] : -INFINITY;
+  for (int i = tid; i < R * R; i += 1024) {
+    const int y = i / R, x = i % R;
+    const int gy = gy0 + y, gx = gx0 + x;
+    s[y * RS + x] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? hb[(size_t)gy * W + gx] : -INFINITY;
   }
   __syncthreads();
-  if (r > 0) {
-    // keep = s == mp(s)
-    pool_rows(s, t0, R, r, tid);
+  // keep = (s == mp(s)), restricted to in-image positions
+  window_pass<RAD, R, RS, SEG, NSEG, true, float>(s, -INFINITY, tid, [&](int i, float m) { t0[i] = m; });
+  __syncthreads();
+  window_pass<RAD, R, RS, SEG, NSEG, false, float>(t0, -INFINITY, tid, [&](int i, float m) {
+    keep[i] = (s[i] == m && s[i] != -INFINITY) ? 1 : 0;
+  });
+  __syncthreads();
+#pragma unroll 1
+  for (int it = 0; it < 2; ++it) {
+    // near = mp(keep) > 0: separable OR of the keep bytes
+    window_pass<RAD, R, RS, SEG, NSEG, true, unsigned char>(keep, (unsigned char)0, tid,
+                                                            [&](int i, unsigned char m) { tb[i] = m & 1; });
     __syncthreads();
-    pool_cols(t0, t1, R, r, tid);
+    window_pass<RAD, R, RS, SEG, NSEG, false, unsigned char>(tb, (unsigned char)0, tid, [&](int i, unsigned char m) {
+      const bool near = m != 0;
+      keep[i] = (keep[i] & 1) | (near ? 2 : 0);
+      const float v = s[i];
+      t0[i] = (v == -INFINITY) ? v : (near ? 0.f : v);  // supp_scores, -inf padding outside the image
+    });
     __syncthreads();
-    for (int i = tid; i < R * R; i += 256) keep[i] = (s[i] == t1[i]) ? 1 : 0;
+    window_pass<RAD, R, RS, SEG, NSEG, true, float>(t0, -INFINITY, tid, [&](int i, float m) { t1[i] = m; });
     __syncthreads();
-    for (int it = 0; it < 2; ++it) {
-      // near = mp(keep) > 0  (t0 <- keep as float with -inf outside the image, pooled into t1)
-      for (int i = tid; i < R * R; i += 256) t1[i] = (s[i] == -INFINITY) ? -INFINITY : (float)keep[i];
-      __syncthreads();
-      pool_rows(t1, t0, R, r, tid);
-      __syncthreads();
-      pool_cols(t0, t1, R, r, tid);
-      __syncthreads();
-      // t0 <- near ? 0 : s  ; remember near in the high bit of keep
-      for (int i = tid; i < R * R; i += 256) {
-        bool near = t1[i] > 0.f;
-        keep[i] = (keep[i] & 1) | (near ? 2 : 0);
-        t0[i] = (s[i] == -INFINITY) ? -INFINITY : (near ? 0.f : s[i]);
-      }
-      __syncthreads();
-      pool_rows(t0, t1, R, r, tid);
-      __syncthreads();
-      // column pool of t1 compared against t0 in place: keep |= (t0 == mp(t0)) & ~near
-      for (int i = tid; i < R * R; i += 256) {
-        int y = i / R, x = i - y * R;
-        float m = -INFINITY;
-        int lo = max(y - r, 0), hi = min(y + r, R - 1);
-        for (int yy = lo; yy <= hi; ++yy) m = fmaxf(m, t1[yy * R + x]);
-        unsigned char k = keep[i];
-        if (!(k & 2) && t0[i] == m) k |= 1;
-        keep[i] = k & 1;
-      }
-      __syncthreads();
-    }
+    window_pass<RAD, R, RS, SEG, NSEG, false, float>(t1, -INFINITY, tid, [&](int i, float m) {
+      unsigned char k = keep[i];
+      if (!(k & 2) && t0[i] == m && s[i] != -INFINITY) k |= 1;
+      keep[i] = k & 1;
+    });
+    __syncthreads();
   }
   int vw = W, vh = H;
   if (valid_wh) { vw = valid_wh[2 * b]; vh = valid_wh[2 * b + 1]; }
   float* ob = out + (size_t)b * H * W;
-  for (int i = tid; i < NT * NT; i += 256) {
-    int y = i / NT, x = i - y * NT;
-    int gy = ty * NT + y, gx = tx * NT + x;
+  for (int i = tid; i < NT * NT; i += 1024) {
+    const int y = i / NT, x = i % NT;
+    const int gy = ty * NT + y, gx = tx * NT + x;
     if (gy >= H || gx >= W) continue;
-    int li = (y + halo) * R + (x + halo);
-    float v = (r > 0) ? (keep[li] ? s[li] : 0.f) : s[li];
+    const int li = (y + HALO) * RS + (x + HALO);
+    float v = keep[li] ? s[li] : 0.f;
     if (border > 0 && (gy < border || gx < border || gy >= vh - border || gx >= vw - border)) v = -1.f;
     ob[(size_t)gy * W + gx] = v;
   }
+}
+
+// radius 0: the pools are identities -> only the border kill remains
+__global__ void nms_r0_kernel(const float* __restrict__ heat, int H, int W, int border,
+                              const int* __restrict__ valid_wh, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)H * W) return;
+  const int gy = (int)(i / W), gx = (int)(i % W);
+  int vw = W, vh = H;
+  if (valid_wh) { vw = valid_wh[2 * b]; vh = valid_wh[2 * b + 1]; }
+  float v = heat[(size_t)b * H * W + i];
+  if (border > 0 && (gy < border || gx < border || gy >= vh - border || gx >= vw - border)) v = -1.f;
+  out[(size_t)b * H * W + i] = v;
+}
+
+template <int RAD>
+static int launch_nms(const float* heat, int B, int H, int W, int border, const int32_t* valid_wh, float* out,
+                      hipStream_t st) {
+  constexpr int R = NT + 10 * RAD, RS = R | 1;
+  const size_t lds = (size_t)R * RS * (3 * sizeof(float) + 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)nms_kernel<RAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  dim3 grid(((W + NT - 1) / NT) * ((H + NT - 1) / NT), B);
+  hipLaunchKernelGGL(nms_kernel<RAD>, grid, dim3(1024), lds, st, heat, H, W, border, valid_wh, out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
 }
 
 extern "C" int gfc_sp_nms(const float* heatmap, int B, int H, int W, int radius, int border,
                           const int32_t* valid_wh, float* out, void* stream) {
   if (!heatmap || !out || B <= 0 || H <= 0 || W <= 0 || radius < 0 || border < 0) return GFC_ERR_INVALID;
   if (radius > NR_MAX) return GFC_ERR_UNSUPPORTED;
-  dim3 grid(((W + NT - 1) / NT) * ((H + NT - 1) / NT), B);
-  hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, (hipStream_t)stream, heatmap, H, W, radius, border, valid_wh, out);
-  GFC_LAUNCH_CHECK();
-  return GFC_OK;
+  hipStream_t st = (hipStream_t)stream;
+  switch (radius) {
+    case 0: {
+      dim3 grid((unsigned)(((long long)H * W + 255) / 256), B);
+      hipLaunchKernelGGL(nms_r0_kernel, grid, dim3(256), 0, st, heatmap, H, W, border, valid_wh, out);
+      GFC_LAUNCH_CHECK();
+      return GFC_OK;
+    }
+    case 1: return launch_nms<1>(heatmap, B, H, W, border, valid_wh, out, st);
+    case 2: return launch_nms<2>(heatmap, B, H, W, border, valid_wh, out, st);
+    case 3: return launch_nms<3>(heatmap, B, H, W, border, valid_wh, out, st);
+    default: return launch_nms<4>(heatmap, B, H, W, border, valid_wh, out, st);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

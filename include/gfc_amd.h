@@ -190,6 +190,8 @@ typedef struct {
    * new row s*256 + h*64 + d  <-  state-dict row h*192 + d*3 + s   (lightglue.py:157-159) */
   const float* wqkv[GFC_LG_MAX_LAYERS];
   const float* bqkv[GFC_LG_MAX_LAYERS];
+  /* out_proj.  NULL = folded into s_ffn0_w at load time (no GEMM of its own):
+   *   ffn0(cat[x, out_proj(ctx)]) = [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)   (lightglue.py:163-164) */
   const float* s_out_w[GFC_LG_MAX_LAYERS];
   const float* s_out_b[GFC_LG_MAX_LAYERS];
   const float* s_ffn0_w[GFC_LG_MAX_LAYERS]; /* [512][512] */
@@ -201,7 +203,7 @@ typedef struct {
   /* cross block.  c_qkv_w = [to_qk ; to_v] stacked to [512][256] */
   const float* c_qkv_w[GFC_LG_MAX_LAYERS];
   const float* c_qkv_b[GFC_LG_MAX_LAYERS];
-  const float* c_out_w[GFC_LG_MAX_LAYERS];
+  const float* c_out_w[GFC_LG_MAX_LAYERS]; /* to_out; NULL = folded into c_ffn0_w (lightglue.py:219-222) */
   const float* c_out_b[GFC_LG_MAX_LAYERS];
   const float* c_ffn0_w[GFC_LG_MAX_LAYERS];
   const float* c_ffn0_b[GFC_LG_MAX_LAYERS];

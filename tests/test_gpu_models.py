@@ -136,6 +136,9 @@ def test_lightglue_golden(golden):
     pred = m0(lg_data(g))
     assert torch.equal(pred["matches0"].cpu(), g["th0_matches0"])
     assert torch.equal(pred["matches1"].cpu(), g["th0_matches1"])
+    # un-folded graph (out_proj / to_out as GEMMs of their own): same results
+    mu = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "fold_out_proj": False}).eval().to(DEV)
+    check_lg(mu(lg_data(g)), g, "b2_")
     # ragged pair (M != N)
     d = lg_data(g, slice(0, 1))
     d["keypoints0"], d["descriptors0"] = d["keypoints0"][:, :100].contiguous(), d["descriptors0"][:, :100].contiguous()

@@ -1,0 +1,142 @@
+"""Micro-benchmarks of the individual kernels at the shapes of the benchmark configuration
+(32 VGA pairs, 1024 keypoints), through the C ABI.  Run on the GPU box:
+    python tools/bench_kernels.py [--only gemm|conv|attn]
+Prints one line per case: time, TFLOP/s, fraction of the fp32-MFMA peak."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from glue_factory_colon_amd import _native as nat  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+PEAK = 157.3
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def report(name, secs, flops):
+    tf = flops / secs / 1e12
+    print(f"{name:58s} {secs * 1e6:9.1f} us  {tf:7.1f} TFLOP/s  {tf / PEAK * 100:5.1f} %", flush=True)
+
+
+def bench_gemm():
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    R = 65536
+    x = torch.randn((R, 256), device=DEV)
+    msg = torch.randn((R, 256), device=DEV)
+    h = torch.randn((R, 512), device=DEV)
+    cos = torch.rand((R, 64), device=DEV)
+    sin = torch.rand((R, 64), device=DEV)
+    cases = [("qkv  N=768 K=256 rotary", x, None, 768, 256, 0, True, False),
+             ("qkv' N=512 K=256", x, None, 512, 256, 0, False, False),
+             ("out  N=256 K=256", x, None, 256, 256, 0, False, False),
+             ("ffn0 N=512 K=256+256 (concat)", x, msg, 512, 256, 256, False, False),
+             ("ffn3 N=256 K=512 residual", h, None, 256, 512, 0, False, True),
+             ("qkv  N=768 K=256 (no rotary)", x, None, 768, 256, 0, False, False)]
+    for name, a0, a1, n, k0, k1, rot, res in cases:
+        w = torch.randn((n, k0 + k1), device=DEV) / 16
+        b = torch.randn((n,), device=DEV)
+        y = torch.empty((R, n), device=DEV)
+        resid = torch.randn((R, n), device=DEV) if res else None
+
+        def fn():
+            nat.check(lib.gfc_linear(nat.ptr(a0), a0.shape[1], k0, nat.ptr(a1), 0 if a1 is None else a1.shape[1], k1,
+                                     nat.ptr(w), k0 + k1, nat.ptr(b), None, None, 1.0, nat.ptr(resid),
+                                     nat.ptr(cos) if rot else None, nat.ptr(sin) if rot else None, 512 if rot else 0,
+                                     nat.ptr(y), n, R, n, st), "linear")
+
+        report(f"gemm[{os.environ.get('GFC_GEMM_NW', 'auto')}] {name}", timeit(fn), 2.0 * R * n * (k0 + k1))
+
+
+def bench_gemm_sweep():
+    """Fixed vs per-K cost: N = 256, K = 256..2048 (synthetic shapes)."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    R = 65536
+    for n in (256, 512):
+        for k in (256, 512, 1024, 2048):
+            a = torch.randn((R, k), device=DEV)
+            w = torch.randn((n, k), device=DEV) / 16
+            b = torch.randn((n,), device=DEV)
+            y = torch.empty((R, n), device=DEV)
+
+            def fn():
+                nat.check(lib.gfc_linear(nat.ptr(a), k, k, None, 0, 0, nat.ptr(w), k, nat.ptr(b), None, None, 1.0,
+                                         None, None, None, 0, nat.ptr(y), n, R, n, st), "linear")
+
+            report(f"gemm[{os.environ.get('GFC_GEMM_NW', 'auto')}] sweep N={n} K={k}", timeit(fn), 2.0 * R * n * k)
+
+
+def bench_conv():
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    B = 32
+    for name, h, w, cin, cout, pool in [("conv1b 64->64 @480x640 +pool", 480, 640, 64, 64, 1),
+                                        ("conv2a 64->64 @240x320", 240, 320, 64, 64, 0),
+                                        ("conv2b 64->64 @240x320 +pool", 240, 320, 64, 64, 1),
+                                        ("conv3a 64->128 @120x160", 120, 160, 64, 128, 0),
+                                        ("conv3b 128->128 @120x160 +pool", 120, 160, 128, 128, 1),
+                                        ("conv4a 128->128 @60x80", 60, 80, 128, 128, 0),
+                                        ("heads 128->512 @60x80", 60, 80, 128, 512, 0)]:
+        x = torch.randn((B, h, w, cin), device=DEV)
+        wt = torch.randn((9, cout, cin), device=DEV) / (3 * cin ** 0.5)
+        bias = torch.randn((cout,), device=DEV)
+        sc = torch.rand((cout,), device=DEV) + 0.5
+        sh = torch.randn((cout,), device=DEV)
+        y = torch.empty((B, h // 2 if pool else h, w // 2 if pool else w, cout), device=DEV)
+
+        def fn():
+            nat.check(lib.gfc_conv3x3(nat.ptr(x), nat.ptr(wt), nat.ptr(bias), nat.ptr(sc), nat.ptr(sh), nat.ptr(y), B,
+                                      h, w, cin, cout, 1, pool, st), "conv")
+
+        report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
+
+
+def bench_attn():
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    B, K = 32, 1024
+    R = 2 * B * K
+    qkv = torch.randn((R, 768), device=DEV)
+    o = torch.empty((R, 256), device=DEV)
+    self_p = torch.tensor([[i * K, K, i * K, K] for i in range(2 * B)], dtype=torch.int32, device=DEV)
+    cross_p = torch.tensor([[i * K, K, (B + i) * K, K] for i in range(B)]
+                           + [[(B + i) * K, K, i * K, K] for i in range(B)], dtype=torch.int32, device=DEV)
+    for name, pt in (("self attention 64 x (1024x1024), 4 heads", self_p), ("cross attention (2 directions)", cross_p)):
+        def fn():
+            nat.check(lib.gfc_attention(nat.ptr(qkv), 768, nat.ptr(qkv[:, 256:]) if False else
+                                        nat.c_void_p(qkv.data_ptr() + 256 * 4), 768,
+                                        nat.c_void_p(qkv.data_ptr() + 512 * 4), 768, nat.ptr(o), 256, nat.ptr(pt),
+                                        2 * B, K, 4, 0.125, st), "attention")
+
+        report(name, timeit(fn), 2 * B * 4 * 2 * 2.0 * K * K * 64)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    if args.only in ("", "gemm"):
+        bench_gemm()
+    if args.only == "sweep":
+        bench_gemm_sweep()
+    if args.only in ("", "conv"):
+        bench_conv()
+    if args.only in ("", "attn"):
+        bench_attn()
