@@ -11,8 +11,8 @@ extractor(view0), extractor(view1), matcher -- the sequence of TwoViewPipeline._
 Every rank processes its own `--pairs` image pairs per step (weak scaling, no data-path
 collective); one RCCL gather of per-pair records closes the job.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: the pooled fp32-MFMA 3x3
-convolution, timed live with HIP events around each launch inside the timed region) and
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel: the fp32-MFMA stem
+convolution conv1a+conv1b+pool, timed live with HIP events around each launch inside the timed region) and
 `cpu_baseline` (the CPU oracle, a PyTorch-CPU port of the reference path, on a bounded sample).
 """
 import argparse
@@ -31,9 +31,9 @@ from glue_factory_colon_amd import lightglue, sharding, superpoint_open, synthet
 
 METRIC = "image-pairs/sec (SuperPoint+LightGlue, 1024 kpts, 640x480)"
 H, W, K = 480, 640, 1024
-# algorithmic FLOPs (2*MAC) of the pooled 3x3 convs per image: conv1b 64->64 @480x640, conv2b 64->64 @240x320,
-# conv3b 128->128 @120x160  (22.65 + 5.66 + 5.66 GFLOP)
-POOL_CONV_FLOPS_PER_IMAGE = 2 * 9 * (64 * 64 * 480 * 640 + 64 * 64 * 240 * 320 + 128 * 128 * 120 * 160)
+# algorithmic FLOPs (2*MAC) of the stem kernel per image: conv1a 1->64 and conv1b 64->64 @480x640
+# (0.35 + 22.65 GFLOP; the halo recomputation of conv1a is not counted)
+STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * 480 * 640
 PAIR_FLOPS = 182.3e9  # whole path per pair at this configuration
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
@@ -120,7 +120,7 @@ def main():
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
-        trace = nat.KernelTrace(6 * args.steps)
+        trace = nat.KernelTrace(2 * args.steps)
         ext._runner.trace = trace
         torch.cuda.synchronize(dev)
         barrier()
@@ -152,7 +152,7 @@ def main():
         n_pairs_total = allrec.shape[0]
         mean_matches = float(allrec[:, 0].mean())
         avg_ms = sum(durs) / max(len(durs), 1)
-        flops_per_launch = POOL_CONV_FLOPS_PER_IMAGE * b / 3.0  # 3 launches of this kernel per extractor call
+        flops_per_launch = STEM_FLOPS_PER_IMAGE * b  # one launch per extractor call (b images)
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if durs else 0.0
         value = world * b * args.steps / elapsed
         out = {
@@ -175,7 +175,7 @@ def main():
                        "weights": "name-seeded seed 0 (no network)", "mean_matches_per_pair": round(mean_matches, 1),
                        "pairs_gathered": n_pairs_total, "final_gather_ms": round(gather_ms, 3),
                        "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true> (3x3 conv + ReLU + BN + 2x2 max-pool)",
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),

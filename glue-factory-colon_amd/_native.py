@@ -52,6 +52,7 @@ SIGNATURES = {
     "gfc_version": (c_char_p, []),
     "gfc_pack_conv3x3": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gfc_conv3x3": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "gfc_sp_stem": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_linear": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
                            c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
                            c_void_p]),

@@ -31,8 +31,10 @@ static SpPlan sp_plan(int B, int C, int H, int W) {
   p.H[1] = H; p.W[1] = W;
   for (int i = 2; i <= 4; ++i) { p.H[i] = p.H[i - 1] / 2; p.W[i] = p.W[i - 1] / 2; }
   p.gray = (C == 3) ? gfc_align((size_t)B * H * W * sizeof(float)) : 0;
-  size_t a = (size_t)B * H * W * 64;
-  size_t a4 = (size_t)B * p.H[4] * p.W[4] * 512;
+  // conv1a never touches HBM (fused into the stem kernel): the largest activation is conv2a's
+  size_t a = (size_t)B * p.H[2] * p.W[2] * 64;
+  size_t a3 = (size_t)B * p.H[3] * p.W[3] * 128, a4 = (size_t)B * p.H[4] * p.W[4] * 512;
+  if (a3 > a) a = a3;
   if (a4 > a) a = a4;
   size_t bsz = (size_t)B * p.H[2] * p.W[2] * 64;
   size_t b3 = (size_t)B * p.H[3] * p.W[3] * 64, b4 = (size_t)B * p.H[4] * p.W[4] * 128;
@@ -64,12 +66,13 @@ extern "C" int gfc_event_elapsed_ms(void* start, void* stop, float* ms) {
   return hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop) == hipSuccess ? GFC_OK : GFC_ERR_LAUNCH;
 }
 
-// pooled conv with optional event bracket (the dominant kernel of the path)
-static int traced_pool_conv(gfc_trace* tr, hipStream_t st, const float* x, const float* w, const float* bias,
-                            const float* scale, const float* shift, float* y, int B, int H, int W, int cin, int cout) {
+// stem (conv1a + conv1b + pool, the dominant kernel of the path) with optional event bracket
+static int traced_stem(gfc_trace* tr, hipStream_t st, const gfc_sp_params* p, const float* x, float* y, int B, int H,
+                       int W) {
   const bool rec = tr && tr->start && tr->stop && tr->count < tr->capacity;
   if (rec && hipEventRecord((hipEvent_t)tr->start[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
-  int s = gfc_conv3x3(x, w, bias, scale, shift, y, B, H, W, cin, cout, 1, 1, st);
+  int s = gfc_sp_stem(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w[1], p->bias[1], p->scale[1], p->shift[1],
+                      y, B, H, W, st);
   if (s != GFC_OK) return s;
   if (rec) {
     if (hipEventRecord((hipEvent_t)tr->stop[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
@@ -97,15 +100,14 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   }
   const int* Hs = pl.H;
   const int* Ws = pl.W;
-  // conv1a, conv1b+pool
-  GFC_TRY(gfc_conv3x3(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], A, B, Hs[1], Ws[1], 1, 64, 1, 0, st));
-  GFC_TRY(traced_pool_conv(trace, st, A, p->w[1], p->bias[1], p->scale[1], p->shift[1], Bf, B, Hs[1], Ws[1], 64, 64));
+  // conv1a + conv1b + pool in one launch (conv1a is recomputed on the halo tile, never written to HBM)
+  GFC_TRY(traced_stem(trace, st, p, x, Bf, B, Hs[1], Ws[1]));
   // conv2a, conv2b+pool
   GFC_TRY(gfc_conv3x3(Bf, p->w[2], p->bias[2], p->scale[2], p->shift[2], A, B, Hs[2], Ws[2], 64, 64, 1, 0, st));
-  GFC_TRY(traced_pool_conv(trace, st, A, p->w[3], p->bias[3], p->scale[3], p->shift[3], Bf, B, Hs[2], Ws[2], 64, 64));
+  GFC_TRY(gfc_conv3x3(A, p->w[3], p->bias[3], p->scale[3], p->shift[3], Bf, B, Hs[2], Ws[2], 64, 64, 1, 1, st));
   // conv3a, conv3b+pool
   GFC_TRY(gfc_conv3x3(Bf, p->w[4], p->bias[4], p->scale[4], p->shift[4], A, B, Hs[3], Ws[3], 64, 128, 1, 0, st));
-  GFC_TRY(traced_pool_conv(trace, st, A, p->w[5], p->bias[5], p->scale[5], p->shift[5], Bf, B, Hs[3], Ws[3], 128, 128));
+  GFC_TRY(gfc_conv3x3(A, p->w[5], p->bias[5], p->scale[5], p->shift[5], Bf, B, Hs[3], Ws[3], 128, 128, 1, 1, st));
   // conv4a, conv4b
   GFC_TRY(gfc_conv3x3(Bf, p->w[6], p->bias[6], p->scale[6], p->shift[6], A, B, Hs[4], Ws[4], 128, 128, 1, 0, st));
   GFC_TRY(gfc_conv3x3(A, p->w[7], p->bias[7], p->scale[7], p->shift[7], Bf, B, Hs[4], Ws[4], 128, 128, 1, 0, st));

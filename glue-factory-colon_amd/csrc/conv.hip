@@ -98,13 +98,24 @@ struct ConvArgs {
   float* y;
   int B, H, W, cin, cout, relu;
   int tiles_x, tiles_y;
+  // STEM variant only: the cin = 1 layer in front (conv1a), recomputed on the halo tile in LDS
+  const float* w1;   // [9][64]
+  const float* b1;
+  const float* s1;   // nullable (no BN)
+  const float* t1;
 };
 
-template <bool POOL>
+// STEM = true: `a.x` is the 1-channel image [B,H,W]; the first layer (1 -> 64, conv + ReLU + BN) is
+// evaluated on the fly for the 18x18 halo pixels from a 20x20 image patch in LDS instead of being
+// read from HBM (superpoint_open.py:100-103: backbone.0.0 feeding backbone.0.1).  This removes the
+// largest activation of the network (B*H*W*64 floats written and read back) and one launch.
+#define CIM (CT + 4)
+template <bool POOL, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* in_s = smem;                   // [CH*CH][CLD]
   float* w_s = smem + CH * CH * CLD;    // [2][CNB][CLD]
+  float* img_s = w_s + 2 * CNB * CLD;   // [CIM*CIM] (STEM only)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -154,6 +165,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
       v_ = *reinterpret_cast<const float4*>(xin + ((size_t)gy_ * a.W + gx_) * cin + (chunk_) * CKC + st_c4); \
     ireg[i_] = v_;                                                                          \
   }
+#define CONV_FILL_IN(chunk_)                                                                \
+  {                                                                                         \
+    const int c0_ = (chunk_) * CKC + st_c4;                                                 \
+    float4 wv_[9];                                                                          \
+    _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                        \
+        wv_[t_] = *reinterpret_cast<const float4*>(a.w1 + t_ * 64 + c0_);                   \
+    const float4 b1_ = *reinterpret_cast<const float4*>(a.b1 + c0_);                        \
+    float4 s1_ = make_float4(1.f, 1.f, 1.f, 1.f), t1_ = make_float4(0.f, 0.f, 0.f, 0.f);   \
+    if (a.s1) {                                                                             \
+      s1_ = *reinterpret_cast<const float4*>(a.s1 + c0_);                                   \
+      t1_ = *reinterpret_cast<const float4*>(a.t1 + c0_);                                   \
+    }                                                                                       \
+    _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                     \
+      const int idx_ = tid + 256 * i_;                                                      \
+      const int p_ = idx_ >> 3;                                                             \
+      const int py_ = p_ / CH, px_ = p_ % CH;                                               \
+      const int gy_ = y0 - 1 + py_, gx_ = x0 - 1 + px_;                                     \
+      float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
+      if (idx_ < CH * CH * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W) {           \
+        _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) {                                  \
+          const float f_ = img_s[(py_ + t_ / 3) * CIM + px_ + t_ % 3];                      \
+          v_.x = fmaf(f_, wv_[t_].x, v_.x);                                                 \
+          v_.y = fmaf(f_, wv_[t_].y, v_.y);                                                 \
+          v_.z = fmaf(f_, wv_[t_].z, v_.z);                                                 \
+          v_.w = fmaf(f_, wv_[t_].w, v_.w);                                                 \
+        }                                                                                   \
+        v_.x = fmaxf(v_.x + b1_.x, 0.f) * s1_.x + t1_.x;                                    \
+        v_.y = fmaxf(v_.y + b1_.y, 0.f) * s1_.y + t1_.y;                                    \
+        v_.z = fmaxf(v_.z + b1_.z, 0.f) * s1_.z + t1_.z;                                    \
+        v_.w = fmaxf(v_.w + b1_.w, 0.f) * s1_.w + t1_.w;                                    \
+      }                                                                                     \
+      ireg[i_] = v_;                                                                        \
+    }                                                                                       \
+  }
 #define CONV_STORE_IN()                                                                     \
   _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                       \
     const int idx_ = tid + 256 * i_;                                                        \
@@ -178,7 +223,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  CONV_LOAD_IN(0);
+  if constexpr (STEM) {
+    // 20x20 image patch around the tile (zero outside the image = conv1a's own zero padding)
+    const float* img = a.x + (size_t)b * a.H * a.W;
+    for (int i = tid; i < CIM * CIM; i += 256) {
+      const int gy = y0 - 2 + i / CIM, gx = x0 - 2 + i % CIM;
+      img_s[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? img[(size_t)gy * a.W + gx] : 0.f;
+    }
+    __syncthreads();
+    CONV_FILL_IN(0);
+  } else {
+    CONV_LOAD_IN(0);
+  }
   CONV_LOAD_W(0);
   CONV_STORE_IN();
   CONV_STORE_W(0);
@@ -189,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     const bool has_next = step + 1 < nsteps;
     const bool new_chunk = has_next && tap == 8;
     if (has_next) CONV_LOAD_W(step + 1);
-    if (new_chunk) { CONV_LOAD_IN(chunk + 1); }
+    if (new_chunk) {
+      if constexpr (STEM) { CONV_FILL_IN(chunk + 1); } else { CONV_LOAD_IN(chunk + 1); }
+    }
 
     const int dy = tap / 3, dx = tap - dy * 3;
     const float* ap = in_s + (dy * CH + dx) * CLD;
@@ -301,6 +359,8 @@ int gfc_rgb_to_gray(const float* img, float* out, int B, int H, int W, hipStream
   return GFC_OK;
 }
 
+static int launch_conv(ConvArgs a, bool pool, bool stem, hipStream_t st);
+
 extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* bias, const float* scale,
                            const float* shift, float* y, int B, int H, int W, int cin, int cout, int relu, int pool,
                            void* stream) {
@@ -319,14 +379,41 @@ extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* b
   ConvArgs a;
   a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
   a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
-  a.tiles_x = (W + CT - 1) / CT;
-  a.tiles_y = (H + CT - 1) / CT;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * B), cout / CNB);
-  size_t lds = (size_t)(CH * CH * CLD + 2 * CNB * CLD) * sizeof(float);
-  if (pool)
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<true>, grid, dim3(256), lds, st, a);
-  else
-    hipLaunchKernelGGL(conv3x3_mfma_kernel<false>, grid, dim3(256), lds, st, a);
+  a.w1 = a.b1 = a.s1 = a.t1 = nullptr;
+  return launch_conv(a, pool != 0, false, st);
+}
+
+static int launch_conv(ConvArgs a, bool pool, bool stem, hipStream_t st) {
+  a.tiles_x = (a.W + CT - 1) / CT;
+  a.tiles_y = (a.H + CT - 1) / CT;
+  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), a.cout / CNB);
+  const size_t lds = (size_t)(CH * CH * CLD + 2 * CNB * CLD + (stem ? CIM * CIM : 0)) * sizeof(float);
+  if (stem) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true, true>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true>), grid, dim3(256), lds, st, a);
+  } else if (pool) {
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false>), grid, dim3(256), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false>), grid, dim3(256), lds, st, a);
+  }
   GFC_LAUNCH_CHECK();
   return GFC_OK;
+}
+
+// conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in one launch: gray image [B,H,W] -> [B,H/2,W/2,64].
+extern "C" int gfc_sp_stem(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
+                           const float* w2_packed, const float* b2, const float* s2, const float* t2, float* y, int B,
+                           int H, int W, void* stream) {
+  if (!image || !w1 || !b1 || !w2_packed || !b2 || !y || B <= 0 || H < 2 || W < 2) return GFC_ERR_INVALID;
+  if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return GFC_ERR_INVALID;
+  ConvArgs a;
+  a.x = image; a.w = w2_packed; a.bias = b2; a.scale = s2; a.shift = t2; a.y = y;
+  a.B = B; a.H = H; a.W = W; a.cin = 64; a.cout = 64; a.relu = 1;
+  a.w1 = w1; a.b1 = b1; a.s1 = s1; a.t1 = t1;
+  return launch_conv(a, true, true, (hipStream_t)stream);
 }

@@ -58,6 +58,15 @@ int gfc_conv3x3(const float* x, const float* w_packed, const float* bias, const 
                 const float* shift, float* y, int B, int H, int W, int cin, int cout, int relu,
                 int pool, void* stream);
 
+/* Extractor stem: conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in ONE launch.  The first layer is
+ * recomputed per workgroup on the 18x18 halo of its 16x16 tile from a 20x20 image patch in LDS, so its
+ * [B,H,W,64] output (the largest activation of the network) never exists in HBM.
+ * image [B,H,W] (one channel), w1 [9][64], w2 packed [9][64][64], y [B,H/2,W/2,64].
+ * Replaces backbone.0 of superpoint_open.py:100-106 / conv1a, conv1b, pool of superpoint.py:214-216. */
+int gfc_sp_stem(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
+                const float* w2_packed, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
+                int W, void* stream);
+
 /* y[M,N] = epilogue( [A0 | A1][M,K0+K1] * W[N,K0+K1]^T + bias ).  Row-major, leading
  * dimensions in floats.  Replaces nn.Linear / 1x1 conv (F.linear -> addmm) at
  * lightglue.py:139-148,158,163-164,181-189 and superpoint_open.py:112-118.
@@ -125,8 +134,8 @@ typedef struct {
 typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;
 
 /* Optional per-launch timing of the dominant kernel (host struct owned by the caller, no global
- * state): gfc_sp_dense brackets every launch of the pooled 3x3 MFMA convolution
- * (conv1b / conv2b / conv3b) with hipEventRecord(start[count]) / hipEventRecord(stop[count]) on the
+ * state): gfc_sp_dense brackets the launch of the stem kernel (gfc_sp_stem: conv1a + conv1b + pool,
+ * 44 % of the extractor's FLOPs) with hipEventRecord(start[count]) / hipEventRecord(stop[count]) on the
  * call's stream and increments count (while count < capacity).  Events come from
  * gfc_event_create().  Used by bench.py for the live roofline figure; NULL in production. */
 typedef struct {

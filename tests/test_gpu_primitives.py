@@ -82,6 +82,38 @@ def test_conv3x3(cin, cout, h, w, pool, bn):
     assert maxerr(y.permute(0, 3, 1, 2), ref) < 2e-5
 
 
+@pytest.mark.parametrize("h,w,bn", [(48, 64, True), (37, 51, True), (32, 32, False)])
+def test_stem_fused_conv1a_conv1b_pool(h, w, bn):
+    lib = nat.lib()
+    g = gen(h * w)
+    b = 2
+    img = torch.rand((b, 1, h, w), generator=g)
+    w1 = torch.randn((64, 1, 3, 3), generator=g) / 3
+    b1 = torch.randn((64,), generator=g) * 0.1
+    w2 = torch.randn((64, 64, 3, 3), generator=g) / 24
+    b2 = torch.randn((64,), generator=g) * 0.1
+    s1 = s2 = t1 = t2 = None
+    ref = F.relu(F.conv2d(img, w1, b1, padding=1))
+    if bn:
+        s1, t1 = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+        s2, t2 = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+        s2[::5] *= -1
+        ref = ref * s1[None, :, None, None] + t1[None, :, None, None]
+    ref = F.relu(F.conv2d(ref, w2, b2, padding=1))
+    if bn:
+        ref = ref * s2[None, :, None, None] + t2[None, :, None, None]
+    ref = F.max_pool2d(ref, 2, 2)
+    w2p = torch.empty((9, 64, 64), device=DEV)
+    nat.check(lib.gfc_pack_conv3x3(nat.ptr(D(w2)), nat.ptr(w2p), 64, 64, st()), "pack")
+    w1p = D(w1.reshape(64, 9).t().contiguous())  # [9][64]
+    y = torch.full((b, h // 2, w // 2, 64), float("nan"), device=DEV)
+    nat.check(lib.gfc_sp_stem(nat.ptr(D(img.reshape(b, h, w))), nat.ptr(w1p), nat.ptr(D(b1)), nat.ptr(D(s1)),
+                              nat.ptr(D(t1)), nat.ptr(w2p), nat.ptr(D(b2)), nat.ptr(D(s2)), nat.ptr(D(t2)), nat.ptr(y),
+                              b, h, w, st()), "stem")
+    torch.cuda.synchronize()
+    assert maxerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
 def test_conv3x3_rejects_bad_shapes():
     lib = nat.lib()
     x = torch.zeros(16, device=DEV)
