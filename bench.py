@@ -38,6 +38,18 @@ PAIR_FLOPS = 182.3e9  # whole path per pair at this configuration
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
+    command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py).  PMC counters
+    cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["conv3x3_mfma_kernel<true, true>"]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(n_pairs: int, iters: int):
     """The oracle (PyTorch-CPU port of the reference path) on the same kind of input, host cores."""
     from oracle import lightglue as olg
@@ -177,7 +189,10 @@ def main():
                        "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
+                         "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of this "
+                                         "command at 32 pairs/step (profiles/r01_pmc_summary.json); algorithmic: "
+                                         "39.3 MB image in + 629.1 MB pooled activation out",
                          "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": flops_per_launch},
         }

@@ -83,6 +83,24 @@ def bench_gemm_sweep():
             report(f"gemm[{os.environ.get('GFC_GEMM_NW', 'auto')}] sweep N={n} K={k}", timeit(fn), 2.0 * R * n * k)
 
 
+def bench_gemm_msweep():
+    """Fixed launch cost vs per-tile cost: N = 256, K = 256, M = 8k .. 512k rows."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    n = k = 256
+    for m in (8192, 16384, 32768, 65536, 131072, 262144, 524288):
+        a = torch.randn((m, k), device=DEV)
+        w = torch.randn((n, k), device=DEV) / 16
+        b = torch.randn((n,), device=DEV)
+        y = torch.empty((m, n), device=DEV)
+
+        def fn():
+            nat.check(lib.gfc_linear(nat.ptr(a), k, k, None, 0, 0, nat.ptr(w), k, nat.ptr(b), None, None, 1.0, None,
+                                     None, None, 0, nat.ptr(y), n, m, n, st), "linear")
+
+        report(f"gemm msweep M={m} N=256 K=256", timeit(fn), 2.0 * m * n * k)
+
+
 def bench_conv():
     lib = nat.lib()
     st = nat.stream_ptr(DEV)
@@ -136,6 +154,8 @@ if __name__ == "__main__":
         bench_gemm()
     if args.only == "sweep":
         bench_gemm_sweep()
+    if args.only == "msweep":
+        bench_gemm_msweep()
     if args.only in ("", "conv"):
         bench_conv()
     if args.only in ("", "attn"):
