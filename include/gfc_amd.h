@@ -255,6 +255,21 @@ int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts
                    float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
                    float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Evaluation ("next" row: the caller right after the matcher)
+ * ---------------------------------------------------------------------------------- */
+
+/* Match metrics against a ground-truth homography, one workgroup per pair, M x N distance matrix never
+ * materialised.  kp0 [B,M,2], kp1 [B,N,2] (pixels), m0 [B,M] int64 (-1 = unmatched), H / Hinv [B,3,3]
+ * (H_0to1 and its inverse, row-major).  out [B,6] = prec@1px, prec@3px, num_matches, num_keypoints,
+ * gt_match_recall@pos_th, gt_match_precision@pos_th;  gt_m0_out (nullable) [B,M] int64 ground-truth
+ * matches (-1 unmatched, -2 ignore).  Replaces eval_matches_homography (gluefactory/eval/utils.py:141-185),
+ * sym_homography_error (geometry/homography.py:314-323), gt_matches_from_homography
+ * (geometry/gt_generation.py:730-801; the evaluation calls it with pos_th = neg_th = 3). */
+int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_t* m0, const float* H,
+                                const float* Hinv, int B, int M, int N, float pos_th, float neg_th, float* out,
+                                int64_t* gt_m0_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -300,7 +300,31 @@ def golden_pipeline():
     save("pipeline", **out)
 
 
+def golden_homography():
+    """Reference geometry used by the HPatches match metrics (gluefactory/geometry/homography.py:161-180,314-344)."""
+    from gluefactory.geometry import homography as ref_h
+
+    g = torch.Generator().manual_seed(17)
+    H = torch.eye(3)[None].repeat(3, 1, 1)
+    H[:, :2, :2] += 0.2 * torch.randn((3, 2, 2), generator=g)
+    H[:, :2, 2] = 30 * torch.randn((3, 2), generator=g)
+    H[:, 2, :2] = 1e-4 * torch.randn((3, 2), generator=g)
+    pts = torch.rand((3, 50, 2), generator=g) * torch.tensor([640.0, 480.0])
+    out = {"H": npy(H), "pts": npy(pts)}
+    out["warp_fwd"] = npy(ref_h.warp_points_torch(pts, H, inverse=False))
+    out["warp_inv"] = npy(ref_h.warp_points_torch(pts, H, inverse=True))
+    noisy = ref_h.warp_points_torch(pts, H, inverse=False) + 2 * torch.randn((3, 50, 2), generator=g)
+    out["pts1"] = npy(noisy)
+    out["sym_err"] = npy(torch.stack([ref_h.sym_homography_error(pts[i], noisy[i], H[i]) for i in range(3)]))
+    H2 = H.clone()
+    H2[:, :2, 2] += 1.5
+    out["corner_err"] = npy(torch.stack([ref_h.homography_corner_error(H2[i], H[i], torch.tensor([640.0, 480.0]))
+                                         for i in range(3)]))
+    save("homography", **out)
+
+
 if __name__ == "__main__":
+    golden_homography()
     golden_nms()
     golden_assignment()
     golden_superpoint_open()
