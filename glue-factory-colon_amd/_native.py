@@ -41,8 +41,8 @@ class LgParams(Structure):
     _fields_ = ([("n_layers", c_int), ("input_dim", c_int), ("input_proj_w", c_void_p), ("input_proj_b", c_void_p),
                  ("posenc_wr", c_void_p)]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in _LG_ARRAYS]
-                + [("final_proj_w", c_void_p), ("final_proj_b", c_void_p), ("matchability_w", c_void_p),
-                   ("matchability_b", c_void_p)])
+                + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in ("final_proj_w", "final_proj_b", "matchability_w",
+                                                               "matchability_b", "token_w", "token_b")])
 
 
 _lib = None
@@ -82,6 +82,13 @@ SIGNATURES = {
     "gfc_lg_filter_matches": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_void_p, c_size_t, c_void_p]),
     "gfc_eval_matches_homography": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 2 + [c_void_p] * 3),
+    "gfc_lg_layer_workspace_bytes": (c_size_t, [c_int]),
+    "gfc_lg_layer": (c_int, [POINTER(LgParams), c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                             c_int, c_void_p, c_size_t, c_void_p]),
+    "gfc_lg_rowdot": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gfc_lg_assign_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_lg_assign": (c_int, [POINTER(LgParams), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
+                      + [c_void_p] * 6 + [c_size_t, c_void_p]),
     "gfc_lg_forward": (c_int, [POINTER(LgParams)] + [c_void_p] * 6 + [c_int] * 3 + [c_float] + [c_void_p] * 8
                        + [c_size_t, c_void_p]),
 }

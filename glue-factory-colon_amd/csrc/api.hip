@@ -128,8 +128,11 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
 // ---------------------------------------------------------------------------------------------
 struct LgPlan {
   size_t R;
-  size_t x, qkv, ctx, msg, hbuf, cosb, sinb, z, stats, filt, tables, total;
+  size_t x, qkv, msg, cosb, sinb, tables, total;
 };
+
+extern "C" size_t gfc_lg_layer_workspace_bytes(int rows);
+extern "C" size_t gfc_lg_assign_workspace_bytes(int B, int M, int N);
 
 static LgPlan lg_plan(int B, int M, int N) {
   LgPlan p;
@@ -137,15 +140,14 @@ static LgPlan lg_plan(int B, int M, int N) {
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += gfc_align(bytes); return o; };
   p.x = take(p.R * 256 * 4);
-  p.qkv = take(p.R * 768 * 4);
-  p.ctx = take(p.R * 256 * 4);
-  p.msg = take(p.R * 256 * 4);
-  p.hbuf = take(p.R * 512 * 4);
+  // stage scratch: one layer's workspace, re-used by the assignment head afterwards
+  size_t stage = gfc_lg_layer_workspace_bytes((int)p.R);
+  const size_t asg = gfc_lg_assign_workspace_bytes(B, M, N);
+  if (asg > stage) stage = asg;
+  p.qkv = take(stage);
+  p.msg = take(p.R * 2 * 4);  // packed key points for the rotary tables
   p.cosb = take(p.R * 64 * 4);
   p.sinb = take(p.R * 64 * 4);
-  p.z = take(p.R * 4);
-  p.stats = take((size_t)2 * B * (M + N) * 4);
-  p.filt = take((size_t)B * (M + N) * 8);
   p.tables = take((size_t)B * (2 * 4 * 2 + 2 + 2 + 4) * 4 + 256);
   p.total = off;
   return p;
@@ -176,6 +178,122 @@ __global__ void lg_tables_kernel(int B, int M, int N, const float* size0, const 
   sizes[2 * (B + b)] = size1[2 * b]; sizes[2 * (B + b) + 1] = size1[2 * b + 1];
 }
 
+// ---- stage entry points (gfc_lg_forward is built from them; the adaptive depth / width path of
+// lightglue.py:500-521 drives them layer by layer from the host) ----
+
+// workspace of one layer: qkv [R,768] | ctx [R,256] | msg [R,256] | hbuf [R,512]
+extern "C" size_t gfc_lg_layer_workspace_bytes(int rows) {
+  if (rows <= 0) return 0;
+  return gfc_align((size_t)rows * 768 * 4) + 2 * gfc_align((size_t)rows * 256 * 4) + gfc_align((size_t)rows * 512 * 4);
+}
+
+extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, int R,
+                            const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
+                            size_t ws_bytes, void* stream) {
+  if (!p || !x || !cosb || !sinb || !self_p || !cross_p || !ws || R <= 0 || n_problems <= 0 || maxn <= 0)
+    return GFC_ERR_INVALID;
+  if (l < 0 || l >= p->n_layers) return GFC_ERR_INVALID;
+  if (ws_bytes < gfc_lg_layer_workspace_bytes(R)) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = 256;
+  char* base = (char*)ws;
+  float* qkv = (float*)base;
+  float* ctx = (float*)(base + gfc_align((size_t)R * 768 * 4));
+  float* msg = (float*)((char*)ctx + gfc_align((size_t)R * 256 * 4));
+  float* hbuf = (float*)((char*)msg + gfc_align((size_t)R * 256 * 4));
+  {
+
+    // ---- self block (lightglue.py:151-164) ----
+    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, nullptr, 1.f, nullptr, cosb, sinb,
+                       512, qkv, 768, R, 768, st));
+    GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, n_problems, maxn, 4, 0.125f, st));
+    // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
+    // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
+    const float* a1s = ctx;
+    if (p->s_out_w[l]) {
+      GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->s_out_w[l], D, p->s_out_b[l], nullptr, nullptr, 1.f, nullptr,
+                         nullptr, nullptr, 0, msg, D, R, D, st));
+      a1s = msg;
+    }
+    GFC_TRY(gfc_linear(x, D, D, a1s, D, D, p->s_ffn0_w[l], 512, p->s_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
+                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
+    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->s_ln_g[l], p->s_ln_b[l], st));
+    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], nullptr, nullptr, 1.f, x,
+                       nullptr, nullptr, 0, x, D, R, D, st));
+    // ---- cross block (lightglue.py:193-222) ----
+    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, 1.f, nullptr, nullptr,
+                       nullptr, 0, qkv, 512, R, 512, st));
+    GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, n_problems, maxn, 4, 0.125f, st));
+    const float* a1c = ctx;
+    if (p->c_out_w[l]) {
+      GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,
+                         nullptr, nullptr, 0, msg, D, R, D, st));
+      a1c = msg;
+    }
+    GFC_TRY(gfc_linear(x, D, D, a1c, D, D, p->c_ffn0_w[l], 512, p->c_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
+                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
+    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->c_ln_g[l], p->c_ln_b[l], st));
+    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], nullptr, nullptr, 1.f, x,
+                       nullptr, nullptr, 0, x, D, R, D, st));
+    }
+  return GFC_OK;
+}
+
+// token confidence / matchability logits: out[row] = (sigmoid?)(x[row,:256] . w + b)   (lightglue.py:69-80,290-291)
+__global__ void sigmoid_inplace_kernel(float* v, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = 1.f / (1.f + expf(-v[i]));
+}
+extern "C" int gfc_lg_rowdot(const float* x, int ld, int rows, const float* w, const float* b, int apply_sigmoid,
+                             float* out, void* stream) {
+  if (!x || !w || !b || !out || rows <= 0 || ld % 4) return GFC_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  GFC_TRY(gfc_rowdot256(x, ld, rows, w, b, out, st));
+  if (apply_sigmoid) {
+    hipLaunchKernelGGL(sigmoid_inplace_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, out, rows);
+    GFC_LAUNCH_CHECK();
+  }
+  return GFC_OK;
+}
+
+// workspace of the assignment head: md [R,256] | z [R] | stats | filter scratch
+extern "C" size_t gfc_lg_assign_workspace_bytes(int B, int M, int N) {
+  if (B <= 0 || M <= 0 || N <= 0) return 0;
+  const size_t R = (size_t)B * (M + N);
+  return gfc_align(R * 256 * 4) + gfc_align(R * 4) + gfc_align(2 * R * 4) + gfc_align(R * 8);
+}
+
+// MatchAssignment of layer l + filter_matches (lightglue.py:279-288,294-319).  x0 [B*M,256], x1 [B*N,256].
+extern "C" int gfc_lg_assign(const gfc_lg_params* p, int l, const float* x0, const float* x1, int B, int M, int N,
+                             float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
+                             void* ws, size_t ws_bytes, void* stream) {
+  if (!p || !x0 || !x1 || !m0 || !m1 || !ms0 || !ms1 || !log_assignment || !ws || B <= 0 || M <= 0 || N <= 0)
+    return GFC_ERR_INVALID;
+  if (l < 0 || l >= p->n_layers || !p->final_proj_w[l] || !p->matchability_w[l]) return GFC_ERR_INVALID;
+  if (ws_bytes < gfc_lg_assign_workspace_bytes(B, M, N)) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int D = 256, R0 = B * M, R1 = B * N;
+  const size_t R = (size_t)R0 + R1;
+  char* base = (char*)ws;
+  float* md = (float*)base;
+  float* z = (float*)(base + gfc_align(R * 256 * 4));
+  float* stats = (float*)((char*)z + gfc_align(R * 4));
+  void* filt = (char*)stats + gfc_align(2 * R * 4);
+  float* md1 = md + (size_t)R0 * D;
+  GFC_TRY(gfc_linear(x0, D, D, nullptr, 0, 0, p->final_proj_w[l], D, p->final_proj_b[l], nullptr, nullptr, 0.25f,
+                     nullptr, nullptr, nullptr, 0, md, D, R0, D, st));
+  GFC_TRY(gfc_linear(x1, D, D, nullptr, 0, 0, p->final_proj_w[l], D, p->final_proj_b[l], nullptr, nullptr, 0.25f,
+                     nullptr, nullptr, nullptr, 0, md1, D, R1, D, st));
+  GFC_TRY(gfc_rowdot256(x0, D, R0, p->matchability_w[l], p->matchability_b[l], z, st));
+  GFC_TRY(gfc_rowdot256(x1, D, R1, p->matchability_w[l], p->matchability_b[l], z + R0, st));
+  GFC_TRY(gfc_batched_nt(md, D, (long long)M * D, md1, D, (long long)N * D, log_assignment, N + 1,
+                         (long long)(M + 1) * (N + 1), M, N, D, B, st));
+  GFC_TRY(gfc_assign_inplace(log_assignment, z, z + R0, B, M, N, stats, st));
+  GFC_TRY(gfc_lg_filter_matches(log_assignment, B, M, N, threshold, m0, m1, ms0, ms1, filt, (size_t)B * (M + N) * 8,
+                                st));
+  return GFC_OK;
+}
+
 extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,
                               const float* desc1, const float* size0, const float* size1, int B, int M, int N,
                               float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1,
@@ -191,15 +309,9 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
   const LgPlan pl = lg_plan(B, M, N);
   char* base = (char*)ws;
   float* x = (float*)(base + pl.x);
-  float* qkv = (float*)(base + pl.qkv);
-  float* ctx = (float*)(base + pl.ctx);
   float* msg = (float*)(base + pl.msg);
-  float* hbuf = (float*)(base + pl.hbuf);
   float* cosb = (float*)(base + pl.cosb);
   float* sinb = (float*)(base + pl.sinb);
-  float* z = (float*)(base + pl.z);
-  float* stats = (float*)(base + pl.stats);
-  void* filt = (void*)(base + pl.filt);
   int* self_p = (int*)(base + pl.tables);
   int* cross_p = self_p + 8 * B;
   int* row0 = cross_p + 8 * B;
@@ -233,40 +345,9 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
   }
 
   const int maxn = M > N ? M : N;
-  for (int l = 0; l < p->n_layers; ++l) {
-    // ---- self block (lightglue.py:151-164) ----
-    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, nullptr, 1.f, nullptr, cosb, sinb,
-                       512, qkv, 768, R, 768, st));
-    GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, 2 * B, maxn, 4, 0.125f, st));
-    // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
-    // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
-    const float* a1s = ctx;
-    if (p->s_out_w[l]) {
-      GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->s_out_w[l], D, p->s_out_b[l], nullptr, nullptr, 1.f, nullptr,
-                         nullptr, nullptr, 0, msg, D, R, D, st));
-      a1s = msg;
-    }
-    GFC_TRY(gfc_linear(x, D, D, a1s, D, D, p->s_ffn0_w[l], 512, p->s_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
-                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
-    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->s_ln_g[l], p->s_ln_b[l], st));
-    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], nullptr, nullptr, 1.f, x,
-                       nullptr, nullptr, 0, x, D, R, D, st));
-    // ---- cross block (lightglue.py:193-222) ----
-    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, 1.f, nullptr, nullptr,
-                       nullptr, 0, qkv, 512, R, 512, st));
-    GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, 2 * B, maxn, 4, 0.125f, st));
-    const float* a1c = ctx;
-    if (p->c_out_w[l]) {
-      GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,
-                         nullptr, nullptr, 0, msg, D, R, D, st));
-      a1c = msg;
-    }
-    GFC_TRY(gfc_linear(x, D, D, a1c, D, D, p->c_ffn0_w[l], 512, p->c_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
-                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
-    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->c_ln_g[l], p->c_ln_b[l], st));
-    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], nullptr, nullptr, 1.f, x,
-                       nullptr, nullptr, 0, x, D, R, D, st));
-  }
+  for (int l = 0; l < p->n_layers; ++l)
+    GFC_TRY(gfc_lg_layer(p, l, x, cosb, sinb, R, self_p, cross_p, 2 * B, maxn, base + pl.qkv,
+                         gfc_lg_layer_workspace_bytes(R), st));
 
   if (ref_desc0 && hipMemcpyAsync(ref_desc0, x, (size_t)R0 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return GFC_ERR_LAUNCH;
@@ -275,14 +356,6 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
     return GFC_ERR_LAUNCH;
 
   // ---- assignment (lightglue.py:279-288) + filter (lightglue.py:294-319) ----
-  float* md = ctx;
-  GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->final_proj_w, D, p->final_proj_b, nullptr, nullptr, 0.25f, nullptr,
-                     nullptr, nullptr, 0, md, D, R, D, st));
-  GFC_TRY(gfc_rowdot256(x, D, R, p->matchability_w, p->matchability_b, z, st));
-  GFC_TRY(gfc_batched_nt(md, D, (long long)M * D, md + (size_t)R0 * D, D, (long long)N * D, log_assignment, N + 1,
-                         (long long)(M + 1) * (N + 1), M, N, D, B, st));
-  GFC_TRY(gfc_assign_inplace(log_assignment, z, z + R0, B, M, N, stats, st));
-  GFC_TRY(gfc_lg_filter_matches(log_assignment, B, M, N, threshold, m0, m1, ms0, ms1, filt, (size_t)B * (M + N) * 8,
-                                st));
-  return GFC_OK;
+  return gfc_lg_assign(p, p->n_layers - 1, x, x + (size_t)R0 * D, B, M, N, threshold, m0, m1, ms0, ms1, log_assignment,
+                       base + pl.qkv, gfc_lg_assign_workspace_bytes(B, M, N), st);
 }

@@ -197,9 +197,12 @@ class LightGlue(nn.Module):
             p.c_ffn0_w[i], p.c_ffn0_b[i] = dev(w0), dev(b0)
             p.c_ln_g[i], p.c_ln_b[i] = dev(ca.ffn[1].weight), dev(ca.ffn[1].bias)
             p.c_ffn3_w[i], p.c_ffn3_b[i] = dev(ca.ffn[3].weight), dev(ca.ffn[3].bias)
-        last = self.log_assignment[conf.n_layers - 1]
-        p.final_proj_w, p.final_proj_b = dev(last.final_proj.weight), dev(last.final_proj.bias)
-        p.matchability_w, p.matchability_b = dev(last.matchability.weight.reshape(-1)), dev(last.matchability.bias)
+        for i, head in enumerate(self.log_assignment):
+            p.final_proj_w[i], p.final_proj_b[i] = dev(head.final_proj.weight), dev(head.final_proj.bias)
+            p.matchability_w[i] = dev(head.matchability.weight.reshape(-1))
+            p.matchability_b[i] = dev(head.matchability.bias)
+        for i, tc in enumerate(self.token_confidence):
+            p.token_w[i], p.token_b[i] = dev(tc.token[0].weight.reshape(-1)), dev(tc.token[0].bias)
         return p, keep, device
 
     # -- forward ------------------------------------------------------------------------
@@ -209,9 +212,6 @@ class LightGlue(nn.Module):
         conf = self.conf
         if self.training:
             raise NotImplementedError("training (loss, checkpointing) is out of scope: inference path only")
-        if conf.depth_confidence > 0 or conf.width_confidence > 0:
-            raise NotImplementedError("adaptive depth / width (early stop, point pruning) is not built; "
-                                      "set depth_confidence = width_confidence = -1")
         if not self.are_weights_initialized:
             raise RuntimeError("LightGlue weights are not loaded (conf.weights or load_state_dict)")
         kpts0, kpts1 = data["keypoints0"], data["keypoints1"]
@@ -228,6 +228,8 @@ class LightGlue(nn.Module):
         desc1 = data["descriptors1"].contiguous().float()
         assert desc0.shape[-1] == conf.input_dim
         assert desc1.shape[-1] == conf.input_dim
+        if (conf.depth_confidence > 0 or conf.width_confidence > 0) and m > 0 and n > 0:
+            return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1)
         m0 = torch.full((b, m), -1, device=device, dtype=torch.long)
         m1 = torch.full((b, n), -1, device=device, dtype=torch.long)
         ms0 = torch.zeros((b, m), device=device)
@@ -260,6 +262,115 @@ class LightGlue(nn.Module):
             "log_assignment": scores,
             "prune0": torch.ones_like(ms0) * conf.n_layers,
             "prune1": torch.ones_like(ms1) * conf.n_layers,
+        }
+
+    # -- adaptive depth / width (lightglue.py:500-521,555-580) -----------------------------------
+    def _forward_adaptive(self, kpts0, kpts1, desc0, desc1, size0, size1):
+        """Early stopping (`depth_confidence`) and point pruning (`width_confidence`); batch size 1 like the
+        reference (`assert b == 1`, lightglue.py:501,507).  The host drives `gfc_lg_layer` layer by layer, takes
+        the stop / prune decisions on the token confidences and matchabilities computed by `gfc_lg_rowdot`
+        (one small device->host read per layer, as `check_if_stop` does in the reference) and re-packs the
+        surviving rows between layers (index_select: plumbing)."""
+        conf, lib = self.conf, nat.lib()
+        b, m, _ = kpts0.shape
+        n = kpts1.shape[1]
+        assert b == 1
+        device = kpts0.device
+        if self._packed is None or self._packed[2] != device:
+            self._packed = self._pack(device)
+        params = self._packed[0]
+        st = nat.stream_ptr(device)
+        d = conf.descriptor_dim
+        do_early_stop, do_prune = conf.depth_confidence > 0, conf.width_confidence > 0
+        # packed rows: image 0 first
+        kp = torch.cat([kpts0[0], kpts1[0]], 0).float().contiguous()
+        x = torch.empty((m + n, d), device=device, dtype=torch.float32)
+        if conf.input_dim == d:
+            x[:m], x[m:] = desc0[0], desc1[0]
+        else:
+            din = conf.input_dim
+            xin = torch.cat([desc0[0], desc1[0]], 0).contiguous()
+            nat.check(lib.gfc_linear(nat.ptr(xin), din, din, None, 0, 0, params.input_proj_w, din, params.input_proj_b,
+                                     None, None, 1.0, None, None, None, 0, nat.ptr(x), d, m + n, d, st), "input_proj")
+        sizes = torch.stack([torch.as_tensor(size0, device=device, dtype=torch.float32).reshape(-1, 2)[0],
+                             torch.as_tensor(size1, device=device, dtype=torch.float32).reshape(-1, 2)[0]]).contiguous()
+        row0 = torch.tensor([0, m], dtype=torch.int32, device=device)
+        cnt = torch.tensor([m, n], dtype=torch.int32, device=device)
+        cos = torch.empty((m + n, 64), device=device)
+        sin = torch.empty((m + n, 64), device=device)
+        nat.check(lib.gfc_lg_posenc(nat.ptr(kp), nat.ptr(sizes), nat.ptr(row0), nat.ptr(cnt), 2, max(m, n),
+                                    params.posenc_wr, nat.ptr(cos), nat.ptr(sin), st), "gfc_lg_posenc")
+        ind0 = torch.arange(m, device=device)
+        ind1 = torch.arange(n, device=device)
+        prune0 = torch.ones((1, m), device=device, dtype=torch.long)
+        prune1 = torch.ones((1, n), device=device, dtype=torch.long)
+        thresholds = self.confidence_thresholds.tolist()
+        cm, cn = m, n
+        last = conf.n_layers - 1
+        for i in range(conf.n_layers):
+            self_p = torch.tensor([[0, cm, 0, cm], [cm, cn, cm, cn]], dtype=torch.int32, device=device)
+            cross_p = torch.tensor([[0, cm, cm, cn], [cm, cn, 0, cm]], dtype=torch.int32, device=device)
+            ws = self._ws.get(lib.gfc_lg_layer_workspace_bytes(cm + cn), device)
+            nat.check(lib.gfc_lg_layer(ctypes.byref(params), i, nat.ptr(x), nat.ptr(cos), nat.ptr(sin), cm + cn,
+                                       nat.ptr(self_p), nat.ptr(cross_p), 2, max(cm, cn), nat.ptr(ws), ws.numel(), st),
+                      "gfc_lg_layer")
+            last = i
+            if i == conf.n_layers - 1:
+                break
+            tok = None
+            if do_early_stop:
+                tok = torch.empty((cm + cn,), device=device)
+                nat.check(lib.gfc_lg_rowdot(nat.ptr(x), d, cm + cn, params.token_w[i], params.token_b[i], 1,
+                                            nat.ptr(tok), st), "gfc_lg_rowdot")
+                # check_if_stop (lightglue.py:569-580): the ratio is taken over the ORIGINAL m + n points
+                ratio = 1.0 - (tok < thresholds[i]).float().sum() / (m + n)
+                if ratio.item() > conf.depth_confidence:
+                    break
+            if do_prune:
+                sc = torch.empty((cm + cn,), device=device)
+                nat.check(lib.gfc_lg_rowdot(nat.ptr(x), d, cm + cn, params.matchability_w[i],
+                                            params.matchability_b[i], 1, nat.ptr(sc), st), "gfc_lg_rowdot")
+                keep = sc > (1 - conf.width_confidence)  # get_pruning_mask, lightglue.py:560-567
+                if tok is not None:
+                    keep = keep | (tok <= thresholds[i])
+                keep0 = torch.where(keep[:cm])[0]
+                keep1 = torch.where(keep[cm:])[0]
+                ind0, ind1 = ind0[keep0], ind1[keep1]
+                rows = torch.cat([keep0, keep1 + cm])
+                x, cos, sin = x[rows].contiguous(), cos[rows].contiguous(), sin[rows].contiguous()
+                prune0[:, ind0] += 1
+                prune1[:, ind1] += 1
+                cm, cn = int(keep0.numel()), int(keep1.numel())
+                if cm == 0 or cn == 0:
+                    break
+        m0 = torch.full((1, m), -1, device=device, dtype=torch.long)
+        m1 = torch.full((1, n), -1, device=device, dtype=torch.long)
+        ms0 = torch.zeros((1, m), device=device)
+        ms1 = torch.zeros((1, n), device=device)
+        scores = torch.zeros((1, cm + 1, cn + 1), device=device)
+        if cm > 0 and cn > 0:
+            pm0 = torch.empty((1, cm), device=device, dtype=torch.long)
+            pm1 = torch.empty((1, cn), device=device, dtype=torch.long)
+            ps0, ps1 = torch.empty((1, cm), device=device), torch.empty((1, cn), device=device)
+            ws = self._ws.get(lib.gfc_lg_assign_workspace_bytes(1, cm, cn), device)
+            x1 = x[cm:]
+            nat.check(lib.gfc_lg_assign(ctypes.byref(params), last, nat.ptr(x), ctypes.c_void_p(x1.data_ptr()), 1, cm,
+                                        cn, float(conf.filter_threshold), nat.ptr(pm0), nat.ptr(pm1), nat.ptr(ps0),
+                                        nat.ptr(ps1), nat.ptr(scores), nat.ptr(ws), ws.numel(), st), "gfc_lg_assign")
+            if do_prune:  # scatter back to the un-pruned indexing (lightglue.py:527-536)
+                m0[:, ind0] = torch.where(pm0 == -1, -1, ind1[pm0.clamp(min=0)])
+                m1[:, ind1] = torch.where(pm1 == -1, -1, ind0[pm1.clamp(min=0)])
+                ms0[:, ind0], ms1[:, ind1] = ps0, ps1
+            else:
+                m0, m1, ms0, ms1 = pm0, pm1, ps0, ps1
+        if not do_prune:
+            prune0 = torch.ones_like(ms0) * conf.n_layers
+            prune1 = torch.ones_like(ms1) * conf.n_layers
+        return {
+            "matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1,
+            "ref_descriptors0": x[None, None, :cm], "ref_descriptors1": x[None, None, cm:],
+            "log_assignment": scores, "prune0": prune0, "prune1": prune1,
+            "stop_layer": torch.full((1,), last + 1, device=device, dtype=torch.long),
         }
 
     def loss(self, pred, data):

@@ -165,3 +165,28 @@ def confidence_thresholds(n_layers=9):
     """Buffer of lightglue.py:555-558."""
     return torch.tensor([min(max(0.8 + 0.1 * math.exp(-4.0 * i / n_layers), 0.0), 1.0) for i in range(n_layers)],
                         dtype=torch.float32)
+
+
+# per-layer mean / std of the un-biased token-confidence and matchability logits of `lightglue_state_dict(0)`
+# on SuperPoint features of the synthetic images (measured once; only used to centre the heads below)
+_TOKEN_MEAN = (-0.12, -0.04, -0.10, 0.32, -0.04, 0.49, -0.32, 0.52)
+_MATCH_MEAN = (-0.09, 0.09, -0.01, 0.00, 0.05, -0.05, 0.00, -0.53)
+_MATCH_STD = (0.06, 0.07, 0.08, 0.06, 0.09, 0.09, 0.09, 0.10)
+
+
+def lightglue_adaptive_state_dict(seed: int = 0, gain: float = 8.0, **kw):
+    """Variant of `lightglue_state_dict` for exercising adaptive depth / width.  With the plain random heads
+    every point of a layer lands on the same side of the thresholds (all kept or all pruned).  Here the
+    token-confidence and matchability heads of layers 0..7 get a larger gain and a per-layer bias that centres
+    them on the decision thresholds (confidence ~0.9, matchability ~0.05), so that per layer about half of
+    the points count as confident and roughly a fifth of those is pruned."""
+    sd = lightglue_state_dict(seed, **kw)
+    for i in range(len(_TOKEN_MEAN)):
+        k = f"token_confidence.{i}.token.0"
+        if k + ".weight" in sd:
+            sd[k + ".weight"] = sd[k + ".weight"] * gain
+            sd[k + ".bias"] = torch.full_like(sd[k + ".bias"], 2.2 - gain * _TOKEN_MEAN[i])
+        k = f"log_assignment.{i}.matchability"
+        sd[k + ".weight"] = sd[k + ".weight"] * gain
+        sd[k + ".bias"] = torch.full_like(sd[k + ".bias"], -2.94 - gain * _MATCH_MEAN[i] + 0.84 * gain * _MATCH_STD[i])
+    return sd

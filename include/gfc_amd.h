@@ -220,11 +220,15 @@ typedef struct {
   const float* c_ln_b[GFC_LG_MAX_LAYERS];
   const float* c_ffn3_w[GFC_LG_MAX_LAYERS];
   const float* c_ffn3_b[GFC_LG_MAX_LAYERS];
-  /* assignment head of the last layer (lightglue.py:524) */
-  const float* final_proj_w; /* [256][256] */
-  const float* final_proj_b;
-  const float* matchability_w; /* [256] */
-  const float* matchability_b; /* [1] */
+  /* assignment heads log_assignment.{i} (lightglue.py:272-291).  gfc_lg_forward uses layer n_layers-1;
+   * the adaptive path (early stop) may read any layer's head, and every layer's matchability for pruning */
+  const float* final_proj_w[GFC_LG_MAX_LAYERS]; /* [256][256] */
+  const float* final_proj_b[GFC_LG_MAX_LAYERS];
+  const float* matchability_w[GFC_LG_MAX_LAYERS]; /* [256] */
+  const float* matchability_b[GFC_LG_MAX_LAYERS]; /* [1] */
+  /* token_confidence.{i}.token.0 (lightglue.py:69-80), i < n_layers-1 */
+  const float* token_w[GFC_LG_MAX_LAYERS]; /* [256] */
+  const float* token_b[GFC_LG_MAX_LAYERS]; /* [1] */
 } gfc_lg_params;
 
 size_t gfc_lg_workspace_bytes(int B, int M, int N);
@@ -245,6 +249,28 @@ int gfc_lg_log_assignment(const float* sim, const float* z0, const float* z1, in
  * ws: B*(M+N)*(4+4) bytes. */
 int gfc_lg_filter_matches(const float* scores, int B, int M, int N, float threshold, int64_t* m0, int64_t* m1,
                           float* ms0, float* ms1, void* ws, size_t ws_bytes, void* stream);
+
+/* One transformer layer (self block on every image + bidirectional cross block, lightglue.py:231-245) on the
+ * packed descriptor rows x [rows,256] (updated in place), with rotary tables cos/sin [rows,64] and attention
+ * problem tables {q_row0, n_q, kv_row0, n_kv} (int32 x4 per entry, n_problems entries each; device).
+ * Building block of gfc_lg_forward; driven layer by layer by the host for adaptive depth / width
+ * (early stop and point pruning, lightglue.py:500-521), where rows are re-packed between layers. */
+size_t gfc_lg_layer_workspace_bytes(int rows);
+int gfc_lg_layer(const gfc_lg_params* p, int layer, float* x, const float* cos_tab, const float* sin_tab, int rows,
+                 const int32_t* self_problems, const int32_t* cross_problems, int n_problems, int max_n, void* ws,
+                 size_t ws_bytes, void* stream);
+
+/* out[row] = x[row,:256] . w + b, optionally through a sigmoid: TokenConfidence (lightglue.py:69-80) and
+ * MatchAssignment.get_matchability (lightglue.py:290-291). */
+int gfc_lg_rowdot(const float* x, int ld, int rows, const float* w, const float* b, int apply_sigmoid, float* out,
+                  void* stream);
+
+/* MatchAssignment of layer `layer` + filter_matches on x0 [B*M,256], x1 [B*N,256]
+ * (lightglue.py:279-288,294-319); outputs as gfc_lg_forward. */
+size_t gfc_lg_assign_workspace_bytes(int B, int M, int N);
+int gfc_lg_assign(const gfc_lg_params* p, int layer, const float* x0, const float* x1, int B, int M, int N,
+                  float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment, void* ws,
+                  size_t ws_bytes, void* stream);
 
 /* Whole matcher: LightGlue.forward (lightglue.py:422-553) with early stop / pruning disabled.
  * kpts0 [B,M,2], kpts1 [B,N,2] (pixel coords), desc0 [B,M,Din], desc1 [B,N,Din],

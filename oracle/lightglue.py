@@ -152,3 +152,72 @@ def match(sd: Dict[str, Tensor], kpts0: Tensor, kpts1: Tensor, desc0: Tensor, de
     if return_layers:
         out["layers"] = layers
     return out
+
+
+def match_adaptive(sd, kpts0, kpts1, desc0, desc1, size0, size1, depth_confidence=-1.0, width_confidence=-1.0,
+                   n_layers=9, heads=4, filter_threshold=0.0):
+    """lightglue.py:422-553 with early stopping (depth_confidence > 0) and point pruning (width_confidence > 0);
+    batch size 1 (lightglue.py:501,507).  When the loop stops before the last layer the reference's in-tree
+    class then fails in torch.stack(all_desc0) (lightglue.py:495-498,547: nothing was appended in eval mode);
+    this restatement returns the descriptors of the stop layer instead and is pinned against the reference
+    only on runs that reach the last layer."""
+    import numpy as np
+
+    with torch.no_grad():
+        b, m, _ = kpts0.shape
+        n = kpts1.shape[1]
+        assert b == 1
+        thr = [float(np.clip(0.8 + 0.1 * np.exp(-4.0 * i / n_layers), 0, 1)) for i in range(n_layers)]
+        thr = torch.tensor(thr, dtype=torch.float32)
+        x0, x1 = desc0.contiguous(), desc1.contiguous()
+        if "input_proj.weight" in sd:
+            x0, x1 = _linear(sd, "input_proj", x0), _linear(sd, "input_proj", x1)
+        e0 = positional_encoding(sd["posenc.Wr.weight"], normalize_keypoints(kpts0, size0))
+        e1 = positional_encoding(sd["posenc.Wr.weight"], normalize_keypoints(kpts1, size1))
+        early, prune = depth_confidence > 0, width_confidence > 0
+        ind0, ind1 = torch.arange(m)[None], torch.arange(n)[None]
+        prune0, prune1 = torch.ones_like(ind0), torch.ones_like(ind1)
+        i = 0
+        for i in range(n_layers):
+            x0 = self_block(sd, f"transformers.{i}.self_attn", x0, e0, heads)
+            x1 = self_block(sd, f"transformers.{i}.self_attn", x1, e1, heads)
+            x0, x1 = cross_block(sd, f"transformers.{i}.cross_attn", x0, x1, heads)
+            if i == n_layers - 1:
+                break
+            t0 = t1 = None
+            if early:
+                t0 = torch.sigmoid(_linear(sd, f"token_confidence.{i}.token.0", x0)).squeeze(-1)
+                t1 = torch.sigmoid(_linear(sd, f"token_confidence.{i}.token.0", x1)).squeeze(-1)
+                conf = torch.cat([t0, t1], -1)
+                ratio = 1.0 - (conf < thr[i]).float().sum() / (m + n)
+                if ratio > depth_confidence:
+                    break
+            if prune:
+                def mask(tok, x):
+                    sc = torch.sigmoid(_linear(sd, f"log_assignment.{i}.matchability", x)).squeeze(-1)
+                    keep = sc > (1 - width_confidence)
+                    if tok is not None:
+                        keep = keep | (tok <= thr[i])
+                    return torch.where(keep)[1]
+
+                k0, k1 = mask(t0, x0), mask(t1, x1)
+                ind0, x0, e0 = ind0.index_select(1, k0), x0.index_select(1, k0), e0.index_select(-2, k0)
+                ind1, x1, e1 = ind1.index_select(1, k1), x1.index_select(1, k1), e1.index_select(-2, k1)
+                prune0[:, ind0] += 1
+                prune1[:, ind1] += 1
+        scores = match_assignment(sd, f"log_assignment.{i}", x0, x1)
+        m0, m1, s0, s1 = filter_matches(scores, filter_threshold)
+        if prune:
+            m0_ = torch.full((b, m), -1, dtype=m0.dtype)
+            m1_ = torch.full((b, n), -1, dtype=m1.dtype)
+            m0_[:, ind0] = torch.where(m0 == -1, -1, ind1.gather(1, m0.clamp(min=0)))
+            m1_[:, ind1] = torch.where(m1 == -1, -1, ind0.gather(1, m1.clamp(min=0)))
+            s0_, s1_ = torch.zeros((b, m)), torch.zeros((b, n))
+            s0_[:, ind0], s1_[:, ind1] = s0, s1
+            m0, m1, s0, s1 = m0_, m1_, s0_, s1_
+        else:
+            prune0 = torch.ones_like(s0) * n_layers
+            prune1 = torch.ones_like(s1) * n_layers
+    return {"matches0": m0, "matches1": m1, "matching_scores0": s0, "matching_scores1": s1, "log_assignment": scores,
+            "prune0": prune0, "prune1": prune1, "stop_layer": i + 1, "ref_descriptors0": x0[:, None],
+            "ref_descriptors1": x1[:, None]}

@@ -300,6 +300,30 @@ def golden_pipeline():
     save("pipeline", **out)
 
 
+def golden_lightglue_adaptive():
+    """Adaptive width (point pruning) and the depth check on a run that reaches the last layer
+    (lightglue.py:500-536,555-580); b == 1."""
+    h, w, k = 120, 160, 160
+    v0, v1, p0, p1 = _features(1, h, w, k, seed=31)
+    size = torch.tensor([[w, h]], dtype=torch.float32)
+    data = {"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"], "descriptors0": p0["descriptors"],
+            "descriptors1": p1["descriptors"], "view0": {"image_size": size}, "view1": {"image_size": size}}
+    out = {"keypoints0": npy(p0["keypoints"]), "keypoints1": npy(p1["keypoints"]),
+           "descriptors0": npy(p0["descriptors"]), "descriptors1": npy(p1["descriptors"]), "image_size": npy(size)}
+    sd = weights.lightglue_adaptive_state_dict(0)
+    for tag, conf in (("prune", {"width_confidence": 0.95}),
+                      ("both", {"width_confidence": 0.95, "depth_confidence": 0.95})):
+        m = ref_lg.LightGlue({"filter_threshold": 0.1, **conf}).eval()
+        m.load_state_dict(sd, strict=False)
+        pred = m(data)
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1", "prune0", "prune1",
+                    "log_assignment"):
+            out[f"{tag}_{key}"] = npy(pred[key])
+        print(tag, "kept", pred["log_assignment"].shape, "matches", int((pred["matches0"] >= 0).sum()),
+              "prune0 hist", torch.bincount(pred["prune0"][0].long()).tolist())
+    save("lightglue_adaptive", **out)
+
+
 def golden_homography():
     """Reference geometry used by the HPatches match metrics (gluefactory/geometry/homography.py:161-180,314-344)."""
     from gluefactory.geometry import homography as ref_h
@@ -325,6 +349,7 @@ def golden_homography():
 
 if __name__ == "__main__":
     golden_homography()
+    golden_lightglue_adaptive()
     golden_nms()
     golden_assignment()
     golden_superpoint_open()

@@ -83,6 +83,25 @@ def test_superpoint_open_padding_and_errors():
         spo(max_num_keypoints=512, detection_threshold=0.0)({"image": im2})
 
 
+@pytest.mark.parametrize("h,w,c", [(203, 331, 3), (97, 136, 1), (480, 641, 1)])
+def test_superpoint_open_odd_sizes_vs_oracle(h, w, c):
+    """HPatches images are resized to short side 480 with an arbitrary long side: sizes that are not
+    multiples of 8 / 16 (floor semantics of the three 2x2 pools, heat-map smaller than the image)."""
+    img = synthetic.synthetic_images(1, h, w, seed=h + w)
+    if c == 3:
+        img = torch.cat([img * 0.8, img, img * 0.9], 1)
+    k = 300
+    m = spo(max_num_keypoints=k, detection_threshold=0.0, nms_radius=3)
+    p = m({"image": img.to(DEV)})
+    o = osp.extract(weights.superpoint_open_state_dict(0), img, "open", nms_radius=3, max_num_keypoints=k,
+                    detection_threshold=0.0)
+    heat, _ = m._runner.dense(m._packed, img.to(DEV))
+    assert heat.shape == o["heatmap"].shape == (1, h // 8 * 8, w // 8 * 8)
+    assert maxerr(heat, o["heatmap"]) < 1e-5
+    compare_keypoints(f"spo_odd_{h}x{w}", p["keypoints"][0], p["keypoint_scores"][0], p["descriptors"][0],
+                      o["keypoints"][0], o["keypoint_scores"][0], o["descriptors"][0], radius=3)
+
+
 # -------------------------------------------------------------------- SuperPoint official
 def test_superpoint_official_golden(golden):
     g = golden("superpoint_official")
@@ -176,6 +195,34 @@ def test_lightglue_layer0_golden(golden):
     pred = m(lg_data(g))
     assert maxerr(pred["ref_descriptors0"][:, 0], g["layer0_desc0"]) < 5e-5
     assert maxerr(pred["ref_descriptors1"][:, 0], g["layer0_desc1"]) < 5e-5
+
+
+def test_lightglue_adaptive_golden_and_early_stop(golden):
+    """Adaptive width against the reference's vectors; adaptive depth (early stop) against the oracle
+    (the reference's in-tree class cannot return from an early stop in eval mode, see oracle docstring)."""
+    g = golden("lightglue_adaptive")
+    sd = weights.lightglue_adaptive_state_dict(0)
+    data = lg_data(g)
+    for tag, conf in (("prune", dict(width_confidence=0.95)), ("both", dict(width_confidence=0.95, depth_confidence=0.95))):
+        m = lightglue.LightGlue({"filter_threshold": 0.1, **conf}).eval()
+        m.load_state_dict(sd, strict=False)
+        pred = m.to(DEV)(data)
+        assert pred["log_assignment"].shape == g[f"{tag}_log_assignment"].shape
+        for key in ("matches0", "matches1", "prune0", "prune1"):
+            assert torch.equal(pred[key].cpu(), g[f"{tag}_{key}"]), (tag, key)
+        assert maxerr(pred["matching_scores0"], g[f"{tag}_matching_scores0"]) < TOL
+        assert int(pred["stop_layer"]) == 9
+    # early stop: a low depth_confidence stops after the first layers
+    m = lightglue.LightGlue({"filter_threshold": 0.1, "depth_confidence": 0.3}).eval()
+    m.load_state_dict(sd, strict=False)
+    pred = m.to(DEV)(data)
+    size = g["image_size"]
+    ref = olg.match_adaptive(sd, g["keypoints0"], g["keypoints1"], g["descriptors0"], g["descriptors1"], size, size,
+                             depth_confidence=0.3, filter_threshold=0.1)
+    assert int(pred["stop_layer"]) == ref["stop_layer"] < 9
+    assert torch.equal(pred["matches0"].cpu(), ref["matches0"]) and torch.equal(pred["matches1"].cpu(), ref["matches1"])
+    assert torch.equal(pred["prune0"].cpu(), ref["prune0"])
+    assert maxerr(pred["ref_descriptors0"], ref["ref_descriptors0"]) < TOL
 
 
 def test_lightglue_empty_set():

@@ -115,8 +115,10 @@ def test_lightglue_rejects_out_of_scope_configs():
     m = lightglue.LightGlue({"weights": "synthetic", "depth_confidence": 0.95}).eval()
     d = {"keypoints0": torch.zeros(1, 4, 2), "keypoints1": torch.zeros(1, 4, 2), "descriptors0": torch.zeros(1, 4, 256),
          "descriptors1": torch.zeros(1, 4, 256)}
-    with pytest.raises(NotImplementedError, match="adaptive"):
-        m(d)
+    with pytest.raises(nat.NativeError, match="no CPU implementation"):  # adaptive path is built, but GPU only
+        m({**d, "view0": {"image_size": torch.ones(1, 2)}, "view1": {"image_size": torch.ones(1, 2)}})
+    with pytest.raises(NotImplementedError, match="training"):
+        lightglue.LightGlue({"weights": "synthetic"}).train()(d)
     with pytest.raises(AssertionError, match="Missing key descriptors1"):
         m({k: v for k, v in d.items() if k != "descriptors1"})
 
