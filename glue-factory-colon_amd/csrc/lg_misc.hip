@@ -315,3 +315,156 @@ extern "C" int gfc_lg_filter_matches(const float* scores, int B, int M, int N, f
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// Nearest-neighbour matcher (reference gluefactory/models/matchers/nearest_neighbor_matcher.py:15-79):
+// top-2 similarities per row / column, ratio and distance tests on d = 2(1 - sim), mutual check.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void top2_insert(float v, int j, float& b1, int& i1, float& b2) {
+  if (v > b1 || (v == b1 && j < i1)) { b2 = b1; b1 = v; i1 = j; } else if (v > b2) { b2 = v; }
+}
+
+// rows: one wave per row -> (best, argbest, second best)
+__global__ __launch_bounds__(256) void nn_top2_rows_kernel(const float* __restrict__ sim, int M, int N,
+                                                           float* __restrict__ best, int* __restrict__ arg,
+                                                           float* __restrict__ second) {
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+  if (i >= M) return;
+  const float* p = sim + ((size_t)b * M + i) * N;
+  float b1 = -INFINITY, b2 = -INFINITY;
+  int i1 = 0x7FFFFFFF;
+  for (int j = lane; j < N; j += 64) top2_insert(p[j], j, b1, i1, b2);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob1 = __shfl_xor(b1, o), ob2 = __shfl_xor(b2, o);
+    const int oi1 = __shfl_xor(i1, o);
+    // merge two (best, second) pairs
+    if (ob1 > b1 || (ob1 == b1 && oi1 < i1)) { b2 = fmaxf(b1, ob2); b1 = ob1; i1 = oi1; } else { b2 = fmaxf(b2, ob1); }
+  }
+  if (lane == 0) { best[(size_t)b * M + i] = b1; arg[(size_t)b * M + i] = i1; second[(size_t)b * M + i] = b2; }
+}
+
+// columns: 32 columns x 8 row groups per block
+__global__ __launch_bounds__(256) void nn_top2_cols_kernel(const float* __restrict__ sim, int M, int N,
+                                                           float* __restrict__ best, int* __restrict__ arg,
+                                                           float* __restrict__ second) {
+  __shared__ float s1[8][32], s2[8][32];
+  __shared__ int si[8][32];
+  const int cx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int j = blockIdx.x * 32 + cx, b = blockIdx.y;
+  const float* p = sim + (size_t)b * M * N;
+  float b1 = -INFINITY, b2 = -INFINITY;
+  int i1 = 0x7FFFFFFF;
+  if (j < N)
+    for (int i = rg; i < M; i += 8) top2_insert(p[(size_t)i * N + j], i, b1, i1, b2);
+  s1[rg][cx] = b1; s2[rg][cx] = b2; si[rg][cx] = i1;
+  __syncthreads();
+  if (rg == 0 && j < N) {
+    for (int g = 1; g < 8; ++g) {
+      const float ob1 = s1[g][cx], ob2 = s2[g][cx];
+      const int oi1 = si[g][cx];
+      if (ob1 > b1 || (ob1 == b1 && oi1 < i1)) { b2 = fmaxf(b1, ob2); b1 = ob1; i1 = oi1; } else { b2 = fmaxf(b2, ob1); }
+    }
+    best[(size_t)b * N + j] = b1; arg[(size_t)b * N + j] = i1; second[(size_t)b * N + j] = b2;
+  }
+}
+
+__device__ __forceinline__ int nn_accept(float s1, float s2, int idx, int ncand, float ratio, float dist_th) {
+  // find_nn, nearest_neighbor_matcher.py:15-31
+  if (ncand == 0) return -1;
+  const float d1 = 2.f * (1.f - s1), d2 = 2.f * (1.f - s2);
+  bool ok = true;
+  if (ratio > 0.f && ncand > 1) ok = ok && (d1 <= (ratio * ratio) * d2);
+  if (dist_th > 0.f) ok = ok && (d1 <= dist_th * dist_th);
+  return ok ? idx : -1;
+}
+
+__global__ void nn_match_kernel(const float* __restrict__ rb, const int* __restrict__ ra, const float* __restrict__ rs,
+                                const float* __restrict__ cb, const int* __restrict__ ca, const float* __restrict__ cs,
+                                int M, int N, float ratio, float dist_th, int mutual, long long* __restrict__ m0,
+                                long long* __restrict__ m1, float* __restrict__ ms0, float* __restrict__ ms1) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  rb += (size_t)b * M; ra += (size_t)b * M; rs += (size_t)b * M;
+  cb += (size_t)b * N; ca += (size_t)b * N; cs += (size_t)b * N;
+  if (t < M) {
+    int a = nn_accept(rb[t], rs[t], ra[t], N, ratio, dist_th);
+    if (mutual && a > -1) {
+      const int back = nn_accept(cb[a], cs[a], ca[a], M, ratio, dist_th);
+      if (back != t) a = -1;
+    }
+    m0[(size_t)b * M + t] = a;
+    ms0[(size_t)b * M + t] = a > -1 ? 1.f : 0.f;
+  }
+  if (t < N) {
+    int a = nn_accept(cb[t], cs[t], ca[t], M, ratio, dist_th);
+    if (mutual && a > -1) {
+      const int back = nn_accept(rb[a], rs[a], ra[a], N, ratio, dist_th);
+      if (back != t) a = -1;
+    }
+    m1[(size_t)b * N + t] = a;
+    ms1[(size_t)b * N + t] = a > -1 ? 1.f : 0.f;
+  }
+}
+
+// la[:, :M, :N] = log_softmax(sim, -1) + log_softmax(sim, -2); last row / column zero
+__global__ __launch_bounds__(256) void nn_log_assignment_kernel(const float* __restrict__ sim, int M, int N,
+                                                                const float* __restrict__ rmax,
+                                                                const float* __restrict__ rlog,
+                                                                const float* __restrict__ cmax,
+                                                                const float* __restrict__ clog,
+                                                                float* __restrict__ out) {
+  const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, b = blockIdx.z;
+  if (j > N) return;
+  float v = 0.f;
+  if (i < M && j < N) {
+    const float x = sim[((size_t)b * M + i) * N + j];
+    v = ((x - rmax[(size_t)b * M + i]) - rlog[(size_t)b * M + i]) +
+        ((x - cmax[(size_t)b * N + j]) - clog[(size_t)b * N + j]);
+  }
+  out[((size_t)b * (M + 1) + i) * (N + 1) + j] = v;
+}
+
+extern "C" size_t gfc_nn_workspace_bytes(int B, int M, int N) {
+  if (B <= 0 || M <= 0 || N <= 0) return 0;
+  return gfc_align((size_t)B * (M + N) * 5 * 4);
+}
+
+extern "C" int gfc_nn_match(const float* desc0, const float* desc1, int B, int M, int N, int D, float ratio_thresh,
+                            float distance_thresh, int mutual, int64_t* m0, int64_t* m1, float* ms0, float* ms1,
+                            float* sim, float* log_assignment, void* ws, size_t ws_bytes, void* stream) {
+  if (!desc0 || !desc1 || !m0 || !m1 || !ms0 || !ms1 || !sim || !ws || B <= 0 || M <= 0 || N <= 0) return GFC_ERR_INVALID;
+  if (D <= 0 || D % 32) return GFC_ERR_UNSUPPORTED;
+  if (ws_bytes < gfc_nn_workspace_bytes(B, M, N)) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  int s = gfc_batched_nt(desc0, D, (long long)M * D, desc1, D, (long long)N * D, sim, N, (long long)M * N, M, N, D, B,
+                         st);
+  if (s != GFC_OK) return s;
+  float* rb = (float*)ws;
+  float* rs = rb + (size_t)B * M;
+  int* ra = (int*)(rs + (size_t)B * M);
+  float* cb = (float*)(ra + (size_t)B * M);
+  float* cs = cb + (size_t)B * N;
+  int* ca = (int*)(cs + (size_t)B * N);
+  float* stats = (float*)(ca + (size_t)B * N);  // 2*(M+N) floats per batch entry
+  hipLaunchKernelGGL(nn_top2_rows_kernel, dim3((M + 3) / 4, B), dim3(256), 0, st, sim, M, N, rb, ra, rs);
+  hipLaunchKernelGGL(nn_top2_cols_kernel, dim3((N + 31) / 32, B), dim3(256), 0, st, sim, M, N, cb, ca, cs);
+  const int mn = M > N ? M : N;
+  hipLaunchKernelGGL(nn_match_kernel, dim3((mn + 255) / 256, B), dim3(256), 0, st, rb, ra, rs, cb, ca, cs, M, N,
+                     ratio_thresh, distance_thresh, mutual, (long long*)m0, (long long*)m1, ms0, ms1);
+  if (log_assignment) {
+    float* rmax = stats;
+    float* rlog = rmax + (size_t)B * M;
+    float* cmax = rlog + (size_t)B * M;
+    float* clog = cmax + (size_t)B * N;
+    hipLaunchKernelGGL(lse_rows_kernel, dim3((M + 3) / 4, B), dim3(256), 0, st, sim, (long long)M * N, N, M, N, rmax,
+                       rlog);
+    hipLaunchKernelGGL(lse_cols_kernel, dim3((N + 31) / 32, B), dim3(256), 0, st, sim, (long long)M * N, N, M, N, cmax,
+                       clog);
+    hipLaunchKernelGGL(nn_log_assignment_kernel, dim3((N + 1 + 255) / 256, M + 1, B), dim3(256), 0, st, sim, M, N,
+                       rmax, rlog, cmax, clog, log_assignment);
+  }
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

@@ -16,6 +16,8 @@ ALIASES = {
     "gluefactory.models.matchers.lightglue": "lightglue",
     "matchers.lightglue_pretrained": "lightglue_pretrained",
     "lightglue_pretrained": "lightglue_pretrained",
+    "matchers.nearest_neighbor_matcher": "nearest_neighbor_matcher",
+    "nearest_neighbor_matcher": "nearest_neighbor_matcher",
     "two_view_pipeline": "two_view_pipeline",
 }
 

@@ -281,6 +281,16 @@ int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts
                    float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
                    float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes, void* stream);
 
+/* Nearest-neighbour matcher ("next" row; the matcher of the reference's superpoint+NN configurations):
+ * sim = desc0 . desc1^T, top-2 per row / column, ratio test d1 <= ratio^2 d2 and distance test d1 <= th^2 on
+ * d = 2(1 - sim) (thresholds <= 0 disable a test), optional mutual check; matching scores are 0/1;
+ * log_assignment (nullable) [B,M+1,N+1] = log_softmax rows + log_softmax columns, zero border.
+ * Replaces NearestNeighborMatcher._forward (gluefactory/models/matchers/nearest_neighbor_matcher.py:15-79). */
+size_t gfc_nn_workspace_bytes(int B, int M, int N);
+int gfc_nn_match(const float* desc0, const float* desc1, int B, int M, int N, int D, float ratio_thresh,
+                 float distance_thresh, int mutual, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* sim,
+                 float* log_assignment, void* ws, size_t ws_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Evaluation ("next" row: the caller right after the matcher)
  * ---------------------------------------------------------------------------------- */

@@ -221,3 +221,33 @@ def match_adaptive(sd, kpts0, kpts1, desc0, desc1, size0, size1, depth_confidenc
     return {"matches0": m0, "matches1": m1, "matching_scores0": s0, "matching_scores1": s1, "log_assignment": scores,
             "prune0": prune0, "prune1": prune1, "stop_layer": i + 1, "ref_descriptors0": x0[:, None],
             "ref_descriptors1": x1[:, None]}
+
+
+def nn_match(desc0, desc1, ratio_thresh=None, distance_thresh=None, mutual_check=True):
+    """NearestNeighborMatcher._forward (gluefactory/models/matchers/nearest_neighbor_matcher.py:15-79)."""
+    def find(sim):
+        if sim.shape[-1] == 0:
+            return sim.new_full(sim.shape[:-1], -1, dtype=torch.long)
+        k = 2 if ratio_thresh and sim.shape[-1] > 1 else 1
+        val, idx = sim.topk(k, dim=-1, largest=True)
+        dist = 2 * (1 - val)
+        ok = torch.ones(idx.shape[:-1], dtype=torch.bool)
+        if ratio_thresh and k > 1:
+            ok = ok & (dist[..., 0] <= ratio_thresh ** 2 * dist[..., 1])
+        if distance_thresh:
+            ok = ok & (dist[..., 0] <= distance_thresh ** 2)
+        return torch.where(ok, idx[..., 0], idx.new_tensor(-1))
+
+    sim = torch.einsum("bnd,bmd->bnm", desc0, desc1)
+    m0, m1 = find(sim), find(sim.transpose(1, 2))
+    if mutual_check and m0.shape[-1] and m1.shape[-1]:
+        i0, i1 = torch.arange(m0.shape[-1]), torch.arange(m1.shape[-1])
+        l0 = torch.gather(m1, -1, m0.clamp(min=0))
+        l1 = torch.gather(m0, -1, m1.clamp(min=0))
+        m0, m1 = (torch.where((m0 > -1) & (i0 == l0), m0, m0.new_tensor(-1)),
+                  torch.where((m1 > -1) & (i1 == l1), m1, m1.new_tensor(-1)))
+    b, m, n = sim.shape
+    la = sim.new_zeros(b, m + 1, n + 1)
+    la[:, :-1, :-1] = F.log_softmax(sim, -1) + F.log_softmax(sim, -2)
+    return {"matches0": m0, "matches1": m1, "matching_scores0": (m0 > -1).float(),
+            "matching_scores1": (m1 > -1).float(), "similarity": sim, "log_assignment": la}

@@ -324,6 +324,25 @@ def golden_lightglue_adaptive():
     save("lightglue_adaptive", **out)
 
 
+def golden_nn_matcher():
+    """NearestNeighborMatcher (matchers/nearest_neighbor_matcher.py) on SuperPoint descriptors."""
+    from gluefactory.models.matchers.nearest_neighbor_matcher import NearestNeighborMatcher
+
+    _, _, p0, p1 = _features(2, 120, 160, 160, seed=31)
+    d0, d1 = p0["descriptors"], p1["descriptors"][:, :140]
+    out = {"descriptors0": npy(d0), "descriptors1": npy(d1)}
+    for tag, conf in (("default", {}), ("ratio", {"ratio_thresh": 0.9}), ("dist", {"distance_thresh": 0.9}),
+                      ("nomutual", {"mutual_check": False, "ratio_thresh": 0.95, "distance_thresh": 1.1})):
+        pred = NearestNeighborMatcher(conf).eval()({"descriptors0": d0, "descriptors1": d1})
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+            out[f"{tag}_{key}"] = npy(pred[key])
+        if tag == "default":
+            out["similarity"] = npy(pred["similarity"])
+            out["log_assignment"] = npy(pred["log_assignment"])
+        print(tag, int((pred["matches0"] >= 0).sum()))
+    save("nn_matcher", **out)
+
+
 def golden_homography():
     """Reference geometry used by the HPatches match metrics (gluefactory/geometry/homography.py:161-180,314-344)."""
     from gluefactory.geometry import homography as ref_h
@@ -350,6 +369,7 @@ def golden_homography():
 if __name__ == "__main__":
     golden_homography()
     golden_lightglue_adaptive()
+    golden_nn_matcher()
     golden_nms()
     golden_assignment()
     golden_superpoint_open()

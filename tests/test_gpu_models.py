@@ -225,6 +225,26 @@ def test_lightglue_adaptive_golden_and_early_stop(golden):
     assert maxerr(pred["ref_descriptors0"], ref["ref_descriptors0"]) < TOL
 
 
+def test_nn_matcher_golden(golden):
+    from glue_factory_colon_amd import nearest_neighbor_matcher as nnm
+    from glue_factory_colon_amd.registry import get_model
+
+    assert get_model("matchers.nearest_neighbor_matcher") is nnm.NearestNeighborMatcher
+    g = golden("nn_matcher")
+    data = {"descriptors0": g["descriptors0"].to(DEV), "descriptors1": g["descriptors1"].to(DEV)}
+    for tag, conf in (("default", {}), ("ratio", {"ratio_thresh": 0.9}), ("dist", {"distance_thresh": 0.9}),
+                      ("nomutual", {"mutual_check": False, "ratio_thresh": 0.95, "distance_thresh": 1.1})):
+        pred = nnm.NearestNeighborMatcher(conf).eval().to(DEV)(data)
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+            assert torch.equal(pred[key].cpu(), g[f"{tag}_{key}"]), (tag, key)
+        if tag == "default":
+            assert maxerr(pred["similarity"], g["similarity"]) < 1e-5
+            assert maxerr(pred["log_assignment"], g["log_assignment"]) < 1e-4
+            assert pred["matches0"].dtype == torch.int64
+    with pytest.raises(AssertionError, match="Missing key descriptors1"):
+        nnm.NearestNeighborMatcher({}).eval()({"descriptors0": data["descriptors0"]})
+
+
 def test_lightglue_empty_set():
     m = lightglue.LightGlue({"weights": "synthetic"}).eval().to(DEV)
     size = torch.tensor([[64.0, 48.0]], device=DEV)

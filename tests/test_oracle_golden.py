@@ -144,3 +144,14 @@ def test_lightglue_adaptive_pruning(golden):
             assert torch.equal(out[key], g[f"{tag}_{key}"]), (tag, key)
         close(out["matching_scores0"], g[f"{tag}_matching_scores0"], 1e-4)
         close(out["log_assignment"], g[f"{tag}_log_assignment"], 1e-3)
+
+
+def test_nn_matcher(golden):
+    g = golden("nn_matcher")
+    for tag, conf in (("default", {}), ("ratio", {"ratio_thresh": 0.9}), ("dist", {"distance_thresh": 0.9}),
+                      ("nomutual", {"mutual_check": False, "ratio_thresh": 0.95, "distance_thresh": 1.1})):
+        out = olg.nn_match(g["descriptors0"], g["descriptors1"], **conf)
+        for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+            assert torch.equal(out[key], g[f"{tag}_{key}"]), (tag, key)
+    close(out["similarity"], g["similarity"], 1e-6)
+    close(olg.nn_match(g["descriptors0"], g["descriptors1"])["log_assignment"], g["log_assignment"], 1e-5)
