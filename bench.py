@@ -6,8 +6,9 @@
 
 Metric (BASELINE.json): image-pairs/sec, SuperPoint + LightGlue, 1024 keypoints, 640x480.
 One "step" = one pass of the hot path over one batch of synthetic pairs resident in HBM:
-extractor(view0), extractor(view1), matcher -- the sequence of TwoViewPipeline._forward
-(reference gluefactory/models/two_view_pipeline.py:278-339) without its per-call device syncs.
+extractor on view0 and view1, then the matcher -- the work of TwoViewPipeline._forward (reference
+gluefactory/models/two_view_pipeline.py:278-339) without its per-call device syncs; by default both views'
+images go through one extractor call of 2*pairs images (--joint-extract 0 = two calls, same results).
 Every rank processes its own `--pairs` image pairs per step (weak scaling, no data-path
 collective); one RCCL gather of per-pair records closes the job.
 
@@ -92,6 +93,39 @@ def cpu_baseline(n_pairs: int, iters: int):
                       f"logical CPUs), {dt:.1f} s timed"}
 
 
+def rehearse_cpu(args):
+    """Same control flow as main() around a dummy step, on gloo / CPU tensors (tests/test_host_cpu.py)."""
+    rank, world, _ = sharding.init_from_env("gloo")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    b = args.pairs
+    pred = {"matches0": torch.full((b, K), -1, dtype=torch.long), "matching_scores0": torch.zeros(b, K),
+            "keypoints0": torch.zeros(b, K, 2), "keypoints1": torch.zeros(b, K, 2)}
+    pred["matches0"][:, : 10 + rank] = 1
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    gathered = sharding.gather_records(sharding.pack_pair_records(pred, K))
+    if rank == 0:
+        allrec = torch.cat(gathered)
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "image-pairs/sec", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
+                          "pairs_gathered": int(allrec.shape[0]),
+                          "matches_per_rank": [int(v) for v in allrec[::b, 0].tolist()]}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,8 +135,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--joint-extract", type=int, default=1,
+                    help="1: run the extractor once on both views' images (2*pairs images per call)")
+    ap.add_argument("--rehearse-cpu", action="store_true",
+                    help="no GPU work: exercise only the multi-process plumbing (rendezvous, barriers, max-reduce, "
+                         "final gather, JSON) on gloo with a dummy step; never a measurement")
     args = ap.parse_args()
 
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
     rank, world, local = sharding.init_from_env("nccl")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
@@ -119,8 +160,16 @@ def main():
     size = torch.tensor([[float(W), float(H)]] * b, device=dev)
     view0, view1 = {"image": v0, "image_size": size}, {"image": v1, "image_size": size}
 
+    both = {"image": torch.cat([v0, v1], 0), "image_size": torch.cat([size, size], 0)}
+
     def step():
-        p0, p1 = ext(view0), ext(view1)
+        if args.joint_extract:
+            # both views through ONE extractor call (images are independent: identical results, fewer launches)
+            pj = ext(both)
+            p0 = {k: v[:b] for k, v in pj.items()}
+            p1 = {k: v[b:] for k, v in pj.items()}
+        else:
+            p0, p1 = ext(view0), ext(view1)
         return p0, p1, mat({"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"],
                             "descriptors0": p0["descriptors"], "descriptors1": p1["descriptors"],
                             "view0": view0, "view1": view1})
@@ -164,7 +213,8 @@ def main():
         n_pairs_total = allrec.shape[0]
         mean_matches = float(allrec[:, 0].mean())
         avg_ms = sum(durs) / max(len(durs), 1)
-        flops_per_launch = STEM_FLOPS_PER_IMAGE * b  # one launch per extractor call (b images)
+        imgs_per_launch = 2 * b if args.joint_extract else b
+        flops_per_launch = STEM_FLOPS_PER_IMAGE * imgs_per_launch  # one stem launch per extractor call
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if durs else 0.0
         value = world * b * args.steps / elapsed
         out = {
@@ -185,7 +235,7 @@ def main():
                        "global_pairs_per_step": b * world, "keypoints": K, "image": [H, W],
                        "parallelism": f"dp{world} (pairs sharded, one final gather)",
                        "weights": "name-seeded seed 0 (no network)", "mean_matches_per_pair": round(mean_matches, 1),
-                       "pairs_gathered": n_pairs_total, "final_gather_ms": round(gather_ms, 3),
+                       "pairs_gathered": n_pairs_total, "extractor_calls_per_step": 1 if args.joint_extract else 2, "final_gather_ms": round(gather_ms, 3),
                        "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

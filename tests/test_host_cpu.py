@@ -227,3 +227,18 @@ def test_dropin_inside_reference_registry():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
     assert r.returncode == 0 and "DROPIN_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_bench_multiprocess_plumbing_rehearsal():
+    """bench.py --gpus 2 launched exactly as the driver does (torch.distributed.run), with --rehearse-cpu:
+    rendezvous on 127.0.0.1, barriers, MAX all-reduce of the elapsed time, the final gather, one JSON line."""
+    import json
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--pairs", "4", "--rehearse-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["pairs_gathered"] == 8 and out["matches_per_rank"] == [10, 11]
