@@ -204,7 +204,9 @@ extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, c
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return GFC_ERR_INVALID;
   // tuning knob (tools/bench_kernels.py): GFC_ATTN_QT=1|2 q-tiles per wave
   static const int forced = [] { const char* e = getenv("GFC_ATTN_QT"); return e ? atoi(e) : 0; }();
-  const int qt = forced ? forced : (max_nq >= 512 ? 2 : 1);
+  // two q-tiles per wave pay off once the grid still fills the chip twice over (256 CUs x 2 workgroups)
+  const long long wgs2 = (long long)((max_nq + 255) / 256) * heads * n_problems;
+  const int qt = forced ? forced : (wgs2 >= 1024 ? 2 : 1);
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
   if (qt == 2) {
