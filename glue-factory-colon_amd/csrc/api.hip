@@ -181,10 +181,15 @@ __global__ void lg_tables_kernel(int B, int M, int N, const float* size0, const 
 // ---- stage entry points (gfc_lg_forward is built from them; the adaptive depth / width path of
 // lightglue.py:500-521 drives them layer by layer from the host) ----
 
-// workspace of one layer: qkv [R,768] | ctx [R,256] | msg [R,256] | hbuf [R,512]
+// workspace of one layer: qkv [R,768] | ctx [R,256] | msg [R,256] | hbuf [R,512] | attention key-split scratch
+// (the scratch is only needed for small row counts; sized for the worst case 2 problems x R/2 queries)
+static size_t lg_attn_scratch_bytes(int rows) {
+  return rows <= 8192 ? gfc_align((size_t)rows * 4 * 8 * 66 * 4) : 0;
+}
 extern "C" size_t gfc_lg_layer_workspace_bytes(int rows) {
   if (rows <= 0) return 0;
-  return gfc_align((size_t)rows * 768 * 4) + 2 * gfc_align((size_t)rows * 256 * 4) + gfc_align((size_t)rows * 512 * 4);
+  return gfc_align((size_t)rows * 768 * 4) + 2 * gfc_align((size_t)rows * 256 * 4) +
+         gfc_align((size_t)rows * 512 * 4) + lg_attn_scratch_bytes(rows);
 }
 
 extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, int R,
@@ -201,12 +206,16 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
   float* ctx = (float*)(base + gfc_align((size_t)R * 768 * 4));
   float* msg = (float*)((char*)ctx + gfc_align((size_t)R * 256 * 4));
   float* hbuf = (float*)((char*)msg + gfc_align((size_t)R * 256 * 4));
+  void* att_ws = (char*)hbuf + gfc_align((size_t)R * 512 * 4);
+  // scratch is indexed [problem][head][max_n queries]: n_problems * maxn <= R for packed rows
+  const size_t att_ws_bytes = ((size_t)n_problems * maxn <= (size_t)R) ? lg_attn_scratch_bytes(R) : 0;
   {
 
     // ---- self block (lightglue.py:151-164) ----
     GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, nullptr, 1.f, nullptr, cosb, sinb,
                        512, qkv, 768, R, 768, st));
-    GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, n_problems, maxn, 4, 0.125f, st));
+    GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, n_problems, maxn, 4, 0.125f, att_ws,
+                          att_ws_bytes, st));
     // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
     // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
     const float* a1s = ctx;
@@ -223,7 +232,8 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
     // ---- cross block (lightglue.py:193-222) ----
     GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, 1.f, nullptr, nullptr,
                        nullptr, 0, qkv, 512, R, 512, st));
-    GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, n_problems, maxn, 4, 0.125f, st));
+    GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, n_problems, maxn, 4, 0.125f, att_ws,
+                          att_ws_bytes, st));
     const float* a1c = ctx;
     if (p->c_out_w[l]) {
       GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,

@@ -25,19 +25,26 @@
 // QT = 32-query tiles per wave (1 or 2): a workgroup covers 128*QT queries.  With QT = 2 every K / V
 // fragment read from LDS feeds two independent score tiles, the barrier count per query halves, and
 // the MFMAs of one tile can issue while the softmax of the other runs on the VALU.
-template <int QT>
-__global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restrict__ Q, int ldq,
+// AW = waves per workgroup (4, or 2 for small problems: twice the workgroups for the same queries).
+template <int QT, int AW>
+__global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(const float* __restrict__ Q, int ldq,
                                                            const float* __restrict__ Kp, int ldk,
                                                            const float* __restrict__ V, int ldv,
                                                            float* __restrict__ O, int ldo,
-                                                           const int4* __restrict__ problems, float scale_log2e) {
+                                                           const int4* __restrict__ problems, float scale_log2e,
+                                                           int ksplit, float* __restrict__ part, int max_nq) {
   // double-buffered K / V tiles: [2][AK*AKLD] keys, then [2][AK*AD] values (67.6 KB -> 2 workgroups / CU)
   __shared__ __attribute__((aligned(16))) float smem[2 * AK * AKLD + 2 * AK * AD];
-  constexpr int AQ = 128 * QT;
+  constexpr int AQ = 32 * AW * QT;
+  constexpr int T = 64 * AW;
+  constexpr int NLD = (AK * AD / 4) / T;  // float4 of K (and of V) per thread per tile
 
   const int4 pb = problems[blockIdx.z];
   const int q_row0 = pb.x, nq = pb.y, kv_row0 = pb.z, nk = pb.w;
-  const int qt0 = blockIdx.x * AQ;
+  // key split (small problems only): blockIdx.x = q-block * ksplit + s; split s walks its share of the key
+  // tiles and leaves an un-normalised partial (O, m, l) for attention_merge_kernel
+  const int ks = blockIdx.x % ksplit;
+  const int qt0 = (blockIdx.x / ksplit) * AQ;
   if (qt0 >= nq) return;  // uniform for the whole workgroup
   const int head = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,49 +72,60 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
     l_run[t] = 0.f;
   }
 
-  const int ntiles = (nk + AK - 1) / AK;
+  const int ntiles_all = (nk + AK - 1) / AK;
+  const int tiles_per = (ntiles_all + ksplit - 1) / ksplit;
+  const int kt0 = ks * tiles_per;
+  const int kt1 = min(ntiles_all, kt0 + tiles_per);
   // staging: thread -> (key = tid>>4 (+16 i), 4 floats at c4); the next tile is prefetched into
   // registers while the current one is multiplied, then written to the other LDS buffer
-  const int st_key = tid >> 4, st_c4 = (tid & 15) * 4;
+  const int st_key = tid >> 4, st_c4 = (tid & 15) * 4;  // keys st_key + (T/16) * i
   const float* kbase = Kp + head * AD + st_c4;
   const float* vbase = V + head * AD + st_c4;
-  float4 kr0, kr1, kr2, kr3, vr0, vr1, vr2, vr3;
-#define ATT_LOAD(kt_)                                                                     \
-  do {                                                                                    \
-    const int kb_ = (kt_) * AK + st_key;                                                  \
-    const size_t r0_ = kv_row0 + min(kb_, nk - 1), r1_ = kv_row0 + min(kb_ + 16, nk - 1); \
-    const size_t r2_ = kv_row0 + min(kb_ + 32, nk - 1), r3_ = kv_row0 + min(kb_ + 48, nk - 1); \
-    kr0 = *reinterpret_cast<const float4*>(kbase + r0_ * ldk);                            \
-    kr1 = *reinterpret_cast<const float4*>(kbase + r1_ * ldk);                            \
-    kr2 = *reinterpret_cast<const float4*>(kbase + r2_ * ldk);                            \
-    kr3 = *reinterpret_cast<const float4*>(kbase + r3_ * ldk);                            \
-    vr0 = *reinterpret_cast<const float4*>(vbase + r0_ * ldv);                            \
-    vr1 = *reinterpret_cast<const float4*>(vbase + r1_ * ldv);                            \
-    vr2 = *reinterpret_cast<const float4*>(vbase + r2_ * ldv);                            \
-    vr3 = *reinterpret_cast<const float4*>(vbase + r3_ * ldv);                            \
+  // named prefetch registers (arrays were demoted to private memory by hipcc)
+  float4 kr0, kr1, kr2, kr3, kr4, kr5, kr6, kr7, vr0, vr1, vr2, vr3, vr4, vr5, vr6, vr7;
+  kr4 = kr5 = kr6 = kr7 = vr4 = vr5 = vr6 = vr7 = make_float4(0.f, 0.f, 0.f, 0.f);
+  static_assert(NLD == 4 || NLD == 8, "staging layout");
+#define ATT_LOAD(kt_)                                                                                                                                                                       \
+  do {                                                                                                                                                                                      \
+    const int kb_ = (kt_) * AK + st_key;                                                                                                                                                    \
+    { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 0, nk - 1); kr0 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr0 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }    \
+    { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 1, nk - 1); kr1 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr1 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }    \
+    { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 2, nk - 1); kr2 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr2 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }    \
+    { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 3, nk - 1); kr3 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr3 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }    \
+    if constexpr (NLD == 8) {                                                                                                                                                               \
+      { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 4, nk - 1); kr4 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr4 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }  \
+      { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 5, nk - 1); kr5 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr5 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }  \
+      { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 6, nk - 1); kr6 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr6 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }  \
+      { const size_t r_ = kv_row0 + min(kb_ + (T / 16) * 7, nk - 1); kr7 = *reinterpret_cast<const float4*>(kbase + r_ * ldk); vr7 = *reinterpret_cast<const float4*>(vbase + r_ * ldv); }  \
+    }                                                                                                                                                                                       \
   } while (0)
-#define ATT_STORE(buf_)                                                                   \
-  do {                                                                                    \
-    float* kd_ = smem + (buf_) * AK * AKLD + st_key * AKLD + st_c4;                       \
-    float* vd_ = smem + 2 * AK * AKLD + (buf_) * AK * AD + st_key * AD + st_c4;           \
-    *reinterpret_cast<float4*>(kd_) = kr0;                                                \
-    *reinterpret_cast<float4*>(kd_ + 16 * AKLD) = kr1;                                    \
-    *reinterpret_cast<float4*>(kd_ + 32 * AKLD) = kr2;                                    \
-    *reinterpret_cast<float4*>(kd_ + 48 * AKLD) = kr3;                                    \
-    *reinterpret_cast<float4*>(vd_) = vr0;                                                \
-    *reinterpret_cast<float4*>(vd_ + 16 * AD) = vr1;                                      \
-    *reinterpret_cast<float4*>(vd_ + 32 * AD) = vr2;                                      \
-    *reinterpret_cast<float4*>(vd_ + 48 * AD) = vr3;                                      \
+#define ATT_STORE(buf_)                                                                                                                                    \
+  do {                                                                                                                                                     \
+    float* kd_ = smem + (buf_) * AK * AKLD + st_c4;                                                                                                        \
+    float* vd_ = smem + 2 * AK * AKLD + (buf_) * AK * AD + st_c4;                                                                                          \
+    { const int key_ = st_key + (T / 16) * 0; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr0; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr0; }    \
+    { const int key_ = st_key + (T / 16) * 1; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr1; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr1; }    \
+    { const int key_ = st_key + (T / 16) * 2; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr2; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr2; }    \
+    { const int key_ = st_key + (T / 16) * 3; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr3; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr3; }    \
+    if constexpr (NLD == 8) {                                                                                                                              \
+      { const int key_ = st_key + (T / 16) * 4; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr4; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr4; }  \
+      { const int key_ = st_key + (T / 16) * 5; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr5; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr5; }  \
+      { const int key_ = st_key + (T / 16) * 6; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr6; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr6; }  \
+      { const int key_ = st_key + (T / 16) * 7; *reinterpret_cast<float4*>(kd_ + key_ * AKLD) = kr7; *reinterpret_cast<float4*>(vd_ + key_ * AD) = vr7; }  \
+    }                                                                                                                                                      \
   } while (0)
 
-  ATT_LOAD(0);
-  ATT_STORE(0);
+  if (kt0 < kt1) {
+    ATT_LOAD(kt0);
+    ATT_STORE(0);
+  }
   __syncthreads();
-  for (int kt = 0; kt < ntiles; ++kt) {
-    const bool has_next = kt + 1 < ntiles;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool has_next = kt + 1 < kt1;
     if (has_next) ATT_LOAD(kt + 1);
-    const float* Ks = smem + (kt & 1) * AK * AKLD;
-    const float* Vs = smem + 2 * AK * AKLD + (kt & 1) * AK * AD;
+    const int buf = (kt - kt0) & 1;
+    const float* Ks = smem + buf * AK * AKLD;
+    const float* Vs = smem + 2 * AK * AKLD + buf * AK * AD;
 
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -175,10 +193,29 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
         }
       }
     }
-    if (has_next) ATT_STORE((kt + 1) & 1);
+    if (has_next) ATT_STORE(buf ^ 1);
     __syncthreads();
   }
 
+  // ---- key-split partials: [problem][head][q][split][64 O | m | l] ----
+  if (part != nullptr) {
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+      if (q[t] < nq) {
+        float* pp = part + ((((size_t)blockIdx.z * gridDim.y + head) * max_nq + q[t]) * ksplit + ks) * 66;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            float* dst = pp + db * 32 + 8 * g + 4 * h;  // 8-byte aligned (66 floats per record)
+            dst[0] = o[t][db][4 * g]; dst[1] = o[t][db][4 * g + 1];
+            dst[2] = o[t][db][4 * g + 2]; dst[3] = o[t][db][4 * g + 3];
+          }
+        if (h == 0) { pp[64] = m_run[t]; pp[65] = l_run[t]; }
+      }
+    }
+    return;
+  }
   // ---- normalise and store: lane holds O[q][db*32 + 8*(r>>2) + 4h + (r&3)] ----
 #pragma unroll
   for (int t = 0; t < QT; ++t) {
@@ -197,26 +234,73 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const float* __restri
   }
 }
 
+// combine the key-split partials: one wave per (query, head); lane = channel
+__global__ __launch_bounds__(256) void attention_merge_kernel(const float* __restrict__ part, float* __restrict__ O,
+                                                              int ldo, const int4* __restrict__ problems, int ksplit,
+                                                              int max_nq, float scale_log2e) {
+  const int4 pb = problems[blockIdx.z];
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6), head = blockIdx.y, lane = threadIdx.x & 63;
+  if (q >= pb.y) return;
+  const float* pp = part + (((size_t)blockIdx.z * gridDim.y + head) * max_nq + q) * ksplit * 66;
+  float m = -INFINITY;
+  for (int s = 0; s < ksplit; ++s) m = fmaxf(m, pp[s * 66 + 64]);
+  float acc = 0.f, l = 0.f;
+  for (int s = 0; s < ksplit; ++s) {
+    const float ms = pp[s * 66 + 64];
+    const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * scale_log2e);
+    acc += w * pp[s * 66 + lane];
+    l += w * pp[s * 66 + 65];
+  }
+  O[(size_t)(pb.x + q) * ldo + head * AD + lane] = acc / l;
+}
+
+// Scratch for the key-split path (0 when the problem set is large enough not to need it).
+extern "C" size_t gfc_attention_workspace_bytes(int n_problems, int max_nq, int heads) {
+  if (n_problems <= 0 || max_nq <= 0 || heads <= 0) return 0;
+  const long long wgs128 = (long long)((max_nq + 127) / 128) * heads * n_problems;
+  if (wgs128 >= 256) return 0;
+  return gfc_align((size_t)n_problems * heads * max_nq * 8 * 66 * sizeof(float));
+}
+
 extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                              int ldo, const int32_t* problems, int n_problems, int max_nq, int heads, float scale,
-                             void* stream) {
+                             void* ws, size_t ws_bytes, void* stream) {
   if (!Q || !K || !V || !O || !problems || n_problems <= 0 || max_nq <= 0 || heads <= 0) return GFC_ERR_INVALID;
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return GFC_ERR_INVALID;
-  // tuning knob (tools/bench_kernels.py): GFC_ATTN_QT=1|2 q-tiles per wave
-  static const int forced = [] { const char* e = getenv("GFC_ATTN_QT"); return e ? atoi(e) : 0; }();
-  // two q-tiles per wave pay off once the grid still fills the chip twice over (256 CUs x 2 workgroups)
-  const long long wgs2 = (long long)((max_nq + 255) / 256) * heads * n_problems;
-  const int qt = forced ? forced : (wgs2 >= 1024 ? 2 : 1);
+  // tuning knob (tools/bench_kernels.py): GFC_ATTN_CFG = 1: 2 q-tiles/wave, 4 waves (256 queries / workgroup)
+  //                                                      2: 1 q-tile/wave, 4 waves (128);  3: 1 q-tile, 2 waves (64)
+  static const int forced = [] { const char* e = getenv("GFC_ATTN_CFG"); return e ? atoi(e) : 0; }();
+  auto wgs = [&](int aq) { return (long long)((max_nq + aq - 1) / aq) * heads * n_problems; };
+  // the largest query block that still fills the chip twice over (256 CUs x 2 workgroups)
+  // (cfg 3, 64 queries per 2-wave workgroup, measured no faster than cfg 2 at batch 1: knob only)
+  const int cfg = forced ? forced : (wgs(256) >= 1024 ? 1 : 2);
   const float sl2 = scale * 1.4426950408889634f;
   hipStream_t st = (hipStream_t)stream;
-  if (qt == 2) {
-    dim3 grid((max_nq + 255) / 256, heads, n_problems);
-    hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo,
-                       reinterpret_cast<const int4*>(problems), sl2);
+  const int4* pt = reinterpret_cast<const int4*>(problems);
+  // key split for small problem sets (batch 1..2): few 128-query blocks cannot fill 1024 SIMDs, so each block's
+  // keys are shared out over up to 8 workgroups and a tiny merge kernel combines the partial soft-maxes
+  static const int forced_split = [] { const char* e = getenv("GFC_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+  int ksplit = 1;
+  if (cfg == 2 && ws != nullptr) {
+    const long long w = wgs(128);
+    int want = forced_split ? forced_split : (w >= 256 ? 1 : (int)((511 + w) / w));
+    if (want > 8) want = 8;
+    while (want > 1 && ws_bytes < (size_t)n_problems * heads * max_nq * want * 66 * sizeof(float)) --want;
+    ksplit = want < 1 ? 1 : want;
+  }
+  if (cfg == 1) {
+    hipLaunchKernelGGL((attention_kernel<2, 4>), dim3((max_nq + 255) / 256, heads, n_problems), dim3(256), 0, st, Q,
+                       ldq, K, ldk, V, ldv, O, ldo, pt, sl2, 1, (float*)nullptr, max_nq);
+  } else if (cfg == 2) {
+    float* part = ksplit > 1 ? (float*)ws : nullptr;
+    hipLaunchKernelGGL((attention_kernel<1, 4>), dim3(((max_nq + 127) / 128) * ksplit, heads, n_problems), dim3(256), 0,
+                       st, Q, ldq, K, ldk, V, ldv, O, ldo, pt, sl2, ksplit, part, max_nq);
+    if (ksplit > 1)
+      hipLaunchKernelGGL(attention_merge_kernel, dim3((max_nq + 3) / 4, heads, n_problems), dim3(256), 0, st, part, O,
+                         ldo, pt, ksplit, max_nq, sl2);
   } else {
-    dim3 grid((max_nq + 127) / 128, heads, n_problems);
-    hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, st, Q, ldq, K, ldk, V, ldv, O, ldo,
-                       reinterpret_cast<const int4*>(problems), sl2);
+    hipLaunchKernelGGL((attention_kernel<1, 2>), dim3((max_nq + 63) / 64, heads, n_problems), dim3(128), 0, st, Q, ldq,
+                       K, ldk, V, ldv, O, ldo, pt, sl2, 1, (float*)nullptr, max_nq);
   }
   GFC_LAUNCH_CHECK();
   return GFC_OK;

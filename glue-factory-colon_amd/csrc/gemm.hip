@@ -14,7 +14,6 @@
 
 #include "common.h"
 
-#define GBM 128
 #define GBK 32
 #define GLD (GBK + 4)
 
@@ -35,14 +34,18 @@ struct GemmArgs {
   float alpha;
 };
 
-// NW = waves along N.  NW = 2: 128x128 tile, 256 threads, 72 KB LDS (2 workgroups / CU).
-//                      NW = 4: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup = 8 waves / CU).
+// 2 x NW waves; every wave owns MT x MT MFMA tiles of 32x32.
+//   MT = 2, NW = 4: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup = 8 waves / CU)   large problems
+//   MT = 2, NW = 2: 128x128 tile, 256 threads,  72 KB LDS (2 workgroups / CU)             narrow N
+//   MT = 1, NW = 2:  64x64  tile, 256 threads,  36 KB LDS (4 workgroups / CU)             small M (batch 1..4):
+//                    4x the workgroups, so that a [2048, 256] GEMM still covers the chip
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
-// underneath the 64 MFMAs per wave of the current one.
-template <int NW>
-__global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
+// underneath the MFMAs of the current one.
+template <int NW, int MT>
+__global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int T = 128 * NW;        // threads
-  constexpr int BN = 64 * NW;        // tile width
+  constexpr int GBM = 64 * MT;       // tile height (2 waves)
+  constexpr int BN = 32 * MT * NW;   // tile width
   constexpr int RPP = T / 8;         // rows staged per pass
   constexpr int NA = GBM / RPP;      // float4 of A per thread per K tile
   constexpr int NB = BN / RPP;       // float4 of W per thread per K tile
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
   const float* w1p = W + (size_t)min(n0 + s_r0 + RPP, g.N - 1) * g.ldw + s_c4;
   const float* w2p = W + (size_t)min(n0 + s_r0 + 2 * RPP, g.N - 1) * g.ldw + s_c4;
   const float* w3p = W + (size_t)min(n0 + s_r0 + 3 * RPP, g.N - 1) * g.ldw + s_c4;
-  static_assert(NB == 4 && (NA == 2 || NA == 4), "staging layout");
+  static_assert((NB == 2 || NB == 4) && (NA == 2 || NA == 4), "staging layout");
   float4 areg0, areg1, areg2, areg3, wreg0, wreg1, wreg2, wreg3;
-  areg2 = areg3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  areg2 = areg3 = wreg2 = wreg3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GEMM_LOAD_TILE(kt)                                                                           \
   do {                                                                                               \
     const int k0_ = (kt) * GBK;                                                                      \
@@ -88,8 +91,10 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
     }                                                                                                \
     wreg0 = *reinterpret_cast<const float4*>(w0p + k0_);                                             \
     wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                                             \
-    wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                                             \
-    wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                                             \
+    if constexpr (NB == 4) {                                                                         \
+      wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                                           \
+      wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                                           \
+    }                                                                                                \
   } while (0)
 #define GEMM_STORE_TILE(buf_)                                                                        \
   do {                                                                                               \
@@ -103,20 +108,23 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
     }                                                                                                \
     *reinterpret_cast<float4*>(bs_) = wreg0;                                                         \
     *reinterpret_cast<float4*>(bs_ + RPP * GLD) = wreg1;                                             \
-    *reinterpret_cast<float4*>(bs_ + 2 * RPP * GLD) = wreg2;                                         \
-    *reinterpret_cast<float4*>(bs_ + 3 * RPP * GLD) = wreg3;                                         \
+    if constexpr (NB == 4) {                                                                         \
+      *reinterpret_cast<float4*>(bs_ + 2 * RPP * GLD) = wreg2;                                       \
+      *reinterpret_cast<float4*>(bs_ + 3 * RPP * GLD) = wreg3;                                       \
+    }                                                                                                \
   } while (0)
 
-  f32x16 acc[2][2];
+  f32x16 acc[MT][MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < MT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  const int a_off = (wm * 64 + l31) * GLD + 4 * h;
-  const int b_off = GBM * GLD + (wn * 64 + l31) * GLD + 4 * h;
+  constexpr int WT = 32 * MT;  // rows / columns per wave
+  const int a_off = (wm * WT + l31) * GLD + 4 * h;
+  const int b_off = GBM * GLD + (wn * WT + l31) * GLD + 4 * h;
 
   GEMM_LOAD_TILE(0);
   GEMM_STORE_TILE(0);
@@ -128,15 +136,16 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
     const float* bp = smem + (kt & 1) * TILE + b_off;
 #pragma unroll
     for (int gk = 0; gk < 4; ++gk) {
-      float4 af[2], bf[2];
-      af[0] = *reinterpret_cast<const float4*>(ap + 8 * gk);
-      af[1] = *reinterpret_cast<const float4*>(ap + 32 * GLD + 8 * gk);
-      bf[0] = *reinterpret_cast<const float4*>(bp + 8 * gk);
-      bf[1] = *reinterpret_cast<const float4*>(bp + 32 * GLD + 8 * gk);
+      float4 af[MT], bf[MT];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * GLD + 8 * gk);
+        bf[mt] = *reinterpret_cast<const float4*>(bp + mt * 32 * GLD + 8 * gk);
+      }
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MT; ++nt) {
           acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
           acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
           acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
@@ -152,18 +161,18 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
     // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
     // measured faster than the LDS transpose below when nothing has to be loaded per element
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = n0 + wn * 64 + nt * 32 + l31;
+    for (int nt = 0; nt < MT; ++nt) {
+      const int col = n0 + wn * WT + nt * 32 + l31;
       const bool col_ok = col < g.N;
       const int cc = col_ok ? col : g.N - 1;
       const float bi = g.bias ? g.bias[cc] : 0.f;
       const float sc = g.scale ? g.scale[cc] : 1.f;
       const float sh = g.shift ? g.shift[cc] : 0.f;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * 64 + mt * 32 + acc_row(r, h);
+          const int row = m0 + wm * WT + mt * 32 + acc_row(r, h);
           float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
           if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
         }
@@ -174,12 +183,14 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
   // Rotary / residual epilogues load per element: in the accumulator layout that is one float per
   // lane per instruction.  Each wave transposes its tile through its own LDS patch instead (the
   // K-loop buffers are free now) and handles whole float4 row segments: 4x fewer loads and stores.
-  constexpr int ELD = 68;  // patch row stride (floats): 32 rows x 64 cols per round
+  constexpr int ELD = WT + 4;        // patch row stride (floats): 32 rows x WT cols per round
+  constexpr int LPR = WT / 4;        // lanes per patch row (one float4 each)
+  constexpr int RPS = 64 / LPR;      // rows per step
   float* patch = smem + wave * 32 * ELD;
   const bool vec_ok = (g.ldy % 4 == 0) && ((reinterpret_cast<size_t>(Y) & 15) == 0) &&
                       (!g.residual || (reinterpret_cast<size_t>(g.residual) & 15) == 0);
-  const int er = lane >> 4, ec = (lane & 15) * 4;  // this lane's row (+4 per step) and 4 columns
-  const int colb = n0 + wn * 64 + ec;
+  const int er = lane / LPR, ec = (lane % LPR) * 4;  // this lane's row (+RPS per step) and 4 columns
+  const int colb = n0 + wn * WT + ec;
   float4 bi4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bi4;
   {
     float* bp4 = reinterpret_cast<float*>(&bi4);
@@ -195,17 +206,17 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
   const bool rot = g.rot_cos != nullptr && colb < g.rot_cols;
   const int rd = colb & 63;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     __syncthreads();  // previous round's reads (or the K loop's) are complete
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < MT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int lr = er + 4 * i;
-      const int row = m0 + wm * 64 + mt * 32 + lr;
+    for (int i = 0; i < 32 / RPS; ++i) {
+      const int lr = er + RPS * i;
+      const int row = m0 + wm * WT + mt * 32 + lr;
       float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
       if (row >= g.M) continue;
       v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
@@ -238,29 +249,36 @@ __global__ __launch_bounds__(128 * NW, 1) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
-template <int NW>
+template <int NW, int MT>
 static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
-  constexpr int BN = 64 * NW;
-  const size_t lds = (size_t)2 * (GBM + BN) * GLD * sizeof(float);
+  constexpr int BM = 64 * MT, BN = 32 * MT * NW;
+  const size_t lds = (size_t)2 * (BM + BN) * GLD * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
     attr_set = true;
   }
-  dim3 grid((g.N + BN - 1) / BN, (g.M + GBM - 1) / GBM, batch);
-  hipLaunchKernelGGL(gemm_nt_kernel<NW>, grid, dim3(128 * NW), lds, st, g);
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
+  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT>), grid, dim3(128 * NW), lds, st, g);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
 
 static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
-  // tuning knob (tools/bench_kernels.py): GFC_GEMM_NW=2|4 forces the tile width
-  static const int forced = [] { const char* e = getenv("GFC_GEMM_NW"); return e ? atoi(e) : 0; }();
-  if (forced == 2) return launch_gemm_t<2>(g, batch, st);
-  if (forced == 4) return launch_gemm_t<4>(g, batch, st);
-  // wide tile whenever N fills it; the 128-wide variant serves narrow outputs (e.g. the 65 detector logits)
-  if (g.N % 256 == 0) return launch_gemm_t<4>(g, batch, st);
-  return launch_gemm_t<2>(g, batch, st);
+  // tuning knob (tools/bench_kernels.py): GFC_GEMM_TILE=1 (128x256) | 2 (128x128) | 3 (64x64)
+  static const int forced = [] { const char* e = getenv("GFC_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
+  int choice = forced;
+  if (!choice) {
+    // largest tile that still gives every CU work; the 128-wide variants need N to fill them
+    if (g.N % 256 == 0 && tiles(128, 256) >= 256) choice = 1;
+    else if (tiles(128, 128) >= 256) choice = 2;
+    else choice = 3;
+  }
+  if (choice == 1) return launch_gemm_t<4, 2>(g, batch, st);
+  if (choice == 2) return launch_gemm_t<2, 2>(g, batch, st);
+  return launch_gemm_t<2, 1>(g, batch, st);
 }
 
 extern "C" int gfc_linear(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W, int ldw,

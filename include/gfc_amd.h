@@ -96,7 +96,10 @@ int gfc_batched_nt(const float* A, int lda, long long strideA, const float* Bm, 
  * directions as two problems, the bidirectional cross attention of lightglue.py:207-217. */
 int gfc_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                   int ldo, const int32_t* problems, int n_problems, int max_nq, int heads, float scale,
-                  void* stream);
+                  void* ws, size_t ws_bytes, void* stream);
+/* Optional scratch (ws may be NULL): small problem sets (batch 1..2) share each query block's keys out over
+ * several workgroups and merge the partial soft-maxes; 0 when the set is large enough not to need it. */
+size_t gfc_attention_workspace_bytes(int n_problems, int max_nq, int heads);
 
 /* In-place LayerNorm(eps 1e-5, affine) + exact (erf) GELU over rows of width 512.
  * Replaces ffn[1], ffn[2] (lightglue.py:143-148). */

@@ -203,9 +203,11 @@ def test_batched_nt():
 
 
 # ----------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("use_ws", [False, True])
 @pytest.mark.parametrize("shapes", [[(128, 128)], [(100, 161), (161, 100)], [(1, 1), (300, 33), (64, 257)],
-                                    [(1024, 1024)]])
-def test_attention(shapes):
+                                    [(1024, 1024)], [(1024, 1024), (1024, 1000)]])
+def test_attention(shapes, use_ws):
+    """use_ws: with scratch the small problem sets take the key-split path (partials + merge kernel)."""
     lib = nat.lib()
     g = gen(len(shapes) + shapes[0][0])
     rows = sum(max(nq, nk) for nq, nk in shapes)
@@ -219,8 +221,15 @@ def test_attention(shapes):
     qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
     o = torch.full((rows, 256), float("nan"), device=DEV)
     pt = torch.tensor(probs, dtype=torch.int32, device=DEV)
+    max_nq = max(s[0] for s in shapes)
+    ws = None
+    if use_ws:
+        nbytes = lib.gfc_attention_workspace_bytes(len(shapes), max_nq, 4)
+        assert nbytes > 0
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
     nat.check(lib.gfc_attention(nat.ptr(qd), 256, nat.ptr(kd), 256, nat.ptr(vd), 256, nat.ptr(o), 256, nat.ptr(pt),
-                                len(shapes), max(s[0] for s in shapes), 4, 0.125, st()), "attention")
+                                len(shapes), max_nq, 4, 0.125, nat.ptr(ws), 0 if ws is None else ws.numel(), st()),
+              "attention")
     torch.cuda.synchronize()
     o = o.cpu()
     for r, nq, _, nk in probs:
@@ -246,7 +255,7 @@ def test_attention_peaky_rows():
     o = torch.empty((n, 256), device=DEV)
     pt = torch.tensor([[0, n, 0, n]], dtype=torch.int32, device=DEV)
     nat.check(lib.gfc_attention(nat.ptr(D(q)), 256, nat.ptr(D(k)), 256, nat.ptr(D(v)), 256, nat.ptr(o),
-                                256, nat.ptr(pt), 1, n, 4, 0.125, st()), "attention")
+                                256, nat.ptr(pt), 1, n, 4, 0.125, None, 0, st()), "attention")
     qq, kk, vv = (t.double().view(n, 4, 64).transpose(0, 1) for t in (q, k, v))
     ref = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(n, 256)
     assert maxerr(o, ref) < 2e-5

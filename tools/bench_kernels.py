@@ -61,7 +61,7 @@ def bench_gemm():
                                      nat.ptr(cos) if rot else None, nat.ptr(sin) if rot else None, 512 if rot else 0,
                                      nat.ptr(y), n, R, n, st), "linear")
 
-        report(f"gemm[{os.environ.get('GFC_GEMM_NW', 'auto')}] {name}", timeit(fn), 2.0 * R * n * (k0 + k1))
+        report(f"gemm[{os.environ.get('GFC_GEMM_TILE', 'auto')}] {name}", timeit(fn), 2.0 * R * n * (k0 + k1))
 
 
 def bench_gemm_sweep():
@@ -80,7 +80,7 @@ def bench_gemm_sweep():
                 nat.check(lib.gfc_linear(nat.ptr(a), k, k, None, 0, 0, nat.ptr(w), k, nat.ptr(b), None, None, 1.0,
                                          None, None, None, 0, nat.ptr(y), n, R, n, st), "linear")
 
-            report(f"gemm[{os.environ.get('GFC_GEMM_NW', 'auto')}] sweep N={n} K={k}", timeit(fn), 2.0 * R * n * k)
+            report(f"gemm[{os.environ.get('GFC_GEMM_TILE', 'auto')}] sweep N={n} K={k}", timeit(fn), 2.0 * R * n * k)
 
 
 def bench_gemm_msweep():
@@ -99,6 +99,25 @@ def bench_gemm_msweep():
                                      None, None, 0, nat.ptr(y), n, m, n, st), "linear")
 
         report(f"gemm msweep M={m} N=256 K=256", timeit(fn), 2.0 * m * n * k)
+
+
+def bench_gemm_small():
+    """Batch-1 shapes (M = 2048 rows): tile choice 1 = 128x256, 2 = 128x128, 3 = 64x64 (GFC_GEMM_TILE)."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    for m in (2048, 8192):
+        for n, k in ((768, 256), (512, 512), (256, 512)):
+            a = torch.randn((m, k), device=DEV)
+            w = torch.randn((n, k), device=DEV) / 16
+            b = torch.randn((n,), device=DEV)
+            y = torch.empty((m, n), device=DEV)
+
+            def fn():
+                nat.check(lib.gfc_linear(nat.ptr(a), k, k, None, 0, 0, nat.ptr(w), k, nat.ptr(b), None, None, 1.0, None,
+                                         None, None, 0, nat.ptr(y), n, m, n, st), "linear")
+
+            report(f"gemm[tile {os.environ.get('GFC_GEMM_TILE', 'auto')}] M={m} N={n} K={k}", timeit(fn, iters=50),
+                   2.0 * m * n * k)
 
 
 def bench_conv():
@@ -141,7 +160,7 @@ def bench_attn():
             nat.check(lib.gfc_attention(nat.ptr(qkv), 768, nat.ptr(qkv[:, 256:]) if False else
                                         nat.c_void_p(qkv.data_ptr() + 256 * 4), 768,
                                         nat.c_void_p(qkv.data_ptr() + 512 * 4), 768, nat.ptr(o), 256, nat.ptr(pt),
-                                        2 * B, K, 4, 0.125, st), "attention")
+                                        2 * B, K, 4, 0.125, None, 0, st), "attention")
 
         report(name, timeit(fn), 2 * B * 4 * 2 * 2.0 * K * K * 64)
 
@@ -156,6 +175,8 @@ if __name__ == "__main__":
         bench_gemm_sweep()
     if args.only == "msweep":
         bench_gemm_msweep()
+    if args.only == "small":
+        bench_gemm_small()
     if args.only in ("", "conv"):
         bench_conv()
     if args.only in ("", "attn"):
