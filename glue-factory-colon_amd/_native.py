@@ -72,6 +72,9 @@ SIGNATURES = {
     "gfc_sp_select_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_sp_select": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_size_t, c_void_p]),
+    "gfc_sp_nms_select_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_sp_nms_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_float, c_int, c_int]
+                          + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "gfc_sp_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                               c_void_p, c_void_p]),
     "gfc_l2norm_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p]),

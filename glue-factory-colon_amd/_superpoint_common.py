@@ -3,6 +3,7 @@ launch sequence dense -> NMS -> select -> (pad) -> sample.  Tensor plumbing only
 happens in libgfc_amd.so.
 """
 import ctypes
+import os
 import time
 
 import torch
@@ -145,6 +146,21 @@ class SuperPointRunner:
                                     nat.stream_ptr(dev)), "gfc_sp_select")
         return kpts, ksc, counts
 
+    def nms_select(self, heat, radius, border, valid_wh, threshold, k):
+        """Fused NMS + top-k (finite k <= 8192): no dense suppressed map, no scan in the selection kernel."""
+        lib = nat.lib()
+        b, h, w = heat.shape
+        dev = heat.device
+        k = int(k)
+        kpts = torch.empty((b, k, 2), device=dev, dtype=torch.float32)
+        ksc = torch.empty((b, k), device=dev, dtype=torch.float32)
+        counts = torch.empty((b,), device=dev, dtype=torch.int32)
+        ws = self.ws_sel.get(lib.gfc_sp_nms_select_workspace_bytes(b, h, w), dev)
+        nat.check(lib.gfc_sp_nms_select(nat.ptr(heat), b, h, w, int(radius), int(border), nat.ptr(valid_wh),
+                                        float(threshold), k, k, None, nat.ptr(kpts), nat.ptr(ksc), nat.ptr(counts),
+                                        nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "gfc_sp_nms_select")
+        return kpts, ksc, counts
+
     def sample(self, desc_raw, kpts, counts, mode):
         lib = nat.lib()
         b, h8, w8, d = desc_raw.shape
@@ -176,11 +192,14 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
     valid_wh = None
     if use_image_size_for_borders and "image_size" in data and remove_borders:
         valid_wh = data["image_size"].to(device=image.device).to(torch.int32).contiguous()
-    suppressed = runner.nms(heat, nms_radius, remove_borders or 0, valid_wh)
-    core_time_ms = (time.perf_counter() - core_start) * 1e3  # like the reference: no device sync
-
     k = max_num_keypoints
-    kpts, ksc, counts = runner.select(suppressed, detection_threshold, k)
+    if k is not None and 0 < k <= 8192 and nms_radius >= 1 and os.environ.get("GFC_SP_FUSED_SELECT", "1") != "0":
+        kpts, ksc, counts = runner.nms_select(heat, nms_radius, remove_borders or 0, valid_wh, detection_threshold, k)
+        core_time_ms = (time.perf_counter() - core_start) * 1e3  # like the reference: no device sync
+    else:  # unlimited number of key points: dense suppressed map + ordered scan
+        suppressed = runner.nms(heat, nms_radius, remove_borders or 0, valid_wh)
+        core_time_ms = (time.perf_counter() - core_start) * 1e3
+        kpts, ksc, counts = runner.select(suppressed, detection_threshold, k)
     if force_num_keypoints:
         if k is None:
             raise ValueError("force_num_keypoints needs max_num_keypoints")

@@ -177,6 +177,15 @@ size_t gfc_sp_select_workspace_bytes(int B, int H, int W);
 int gfc_sp_select(const float* scores, int B, int H, int W, float threshold, int k, int cap, float* kpts,
                   float* kscores, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
 
+/* gfc_sp_nms + gfc_sp_select in one pass over the heat-map: the NMS kernel appends every pixel above the
+ * threshold to the per-image key list (unordered; keys are unique, so the result is still deterministic) and the
+ * selection kernel skips its scan.  nms_out (nullable) receives the suppressed map.
+ * 1 <= k <= 8192, 1 <= radius <= 4 (radius 0 keeps ~all pixels: use the two separate stages). */
+size_t gfc_sp_nms_select_workspace_bytes(int B, int H, int W);
+int gfc_sp_nms_select(const float* heatmap, int B, int H, int W, int radius, int border, const int32_t* valid_wh,
+                      float threshold, int k, int cap, float* nms_out, float* kpts, float* kscores, int32_t* counts,
+                      void* ws, size_t ws_bytes, void* stream);
+
 /* Bilinear sampling of L2-normalised dense descriptors at keypoints + L2 normalisation.
  * desc_raw [B,h,w,D] un-normalised (normalisation over D is applied per corner on the fly),
  * kpts [B,cap,2] integer-valued pixel coordinates, n_kpts [B] (nullable = cap for all),

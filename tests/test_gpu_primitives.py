@@ -323,6 +323,29 @@ def test_select_bit_exact(k):
         assert torch.equal(kp[i, :n], xy) and torch.equal(sc[i, :n], val)
 
 
+@pytest.mark.parametrize("k,r", [(50, 3), (1024, 3), (5000, 4), (300, 1)])
+def test_fused_nms_select_equals_separate_stages(k, r):
+    """gfc_sp_nms_select (candidates emitted by the NMS kernel, unordered) == gfc_sp_nms + gfc_sp_select, bit for bit,
+    in both branches (more than k candidates: top-k sorted; fewer: all, row-major)."""
+    from glue_factory_colon_amd._superpoint_common import SuperPointRunner
+
+    g = gen(k + r)
+    h, w = 150, 200
+    s = torch.rand((3, h, w), generator=g)
+    s[1] = (s[1] * 64).round() / 64  # ties
+    s[2, :, :] = 0.0
+    s[2, 40:44, 50:60] = 0.3
+    run = SuperPointRunner()
+    sd = D(s)
+    wh = D(torch.tensor([[w, h], [w - 7, h - 3], [w, h]], dtype=torch.int32))
+    nms = run.nms(sd, r, 4, wh)
+    kp_a, sc_a, cnt_a = run.select(nms, 0.0, k)
+    kp_b, sc_b, cnt_b = run.nms_select(sd, r, 4, wh, 0.0, k)
+    torch.cuda.synchronize()
+    assert torch.equal(cnt_a, cnt_b) and torch.equal(kp_a, kp_b) and torch.equal(sc_a, sc_b)
+    assert int(cnt_a[2]) < k
+
+
 def test_select_ties_and_empty():
     """Equal scores: lower linear index first (what torch.topk on CPU returns for these inputs is
     not contractual; the HIP rule is documented in the header) -- here checked against a stable sort."""
