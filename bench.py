@@ -46,7 +46,7 @@ def pmc_traffic_bytes():
     path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
     try:
         with open(path) as f:
-            return json.load(f)["conv3x3_mfma_kernel<true, true>"]["hbm_bytes_per_launch"]
+            return json.load(f)["conv3x3_mfma_kernel<true, true>"]["hbm_bytes_per_launch"]  # 64-image launches
     except (OSError, KeyError, ValueError):
         return None
 
@@ -135,7 +135,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=2)
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
                     help="c2 = BASELINE.json configs[1] (640x480, 1024 kpts; the headline metric); "
                          "c4 = configs[3] shape (1024x1024, 2048 kpts) for information")
@@ -253,9 +253,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
-                         "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of this "
-                                         "command at 32 pairs/step (profiles/r01_pmc_summary.json); algorithmic: "
-                                         "39.3 MB image in + 629.1 MB pooled activation out",
+                         "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of the "
+                                         "default command (profiles/r01_pmc_summary.json); algorithmic per launch: "
+                                         f"{imgs_per_launch * H * W * 4 / 1e6:.1f} MB image in + "
+                                         f"{imgs_per_launch * (H // 2) * (W // 2) * 64 * 4 / 1e6:.1f} MB pooled "
+                                         "activation out",
                          "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": flops_per_launch},
         }
