@@ -93,6 +93,37 @@ def cpu_baseline(n_pairs: int, iters: int):
                       f"logical CPUs), {dt:.1f} s timed"}
 
 
+def torch_eager_same_gpu(dev, n_pairs: int = 16, iters: int = 4):
+    """Part of the baseline leg: the same oracle with its tensors on the MI355X, i.e. what the reference's own
+    PyTorch modules do on this GPU under PyTorch-ROCm eager fp32 (MIOpen convolutions, rocBLAS linears, SDPA).
+    Reported for context beside `cpu_baseline`; never the thing shipped."""
+    from oracle import lightglue as olg
+    from oracle import superpoint as osp
+
+    v0, v1 = synthetic.synthetic_pairs(n_pairs, H, W, seed=1234, device=dev)
+    sd_sp = {k: v.to(dev) for k, v in weights.superpoint_open_state_dict(0).items()}
+    sd_lg = {k: v.to(dev) for k, v in weights.lightglue_state_dict(0).items()}
+    size = torch.tensor([[float(W), float(H)]] * n_pairs, device=dev)
+
+    def run():
+        a = osp.extract(sd_sp, v0, "open", nms_radius=3, max_num_keypoints=K, detection_threshold=0.0)
+        b = osp.extract(sd_sp, v1, "open", nms_radius=3, max_num_keypoints=K, detection_threshold=0.0)
+        return olg.match(sd_lg, torch.stack(a["keypoints"]), torch.stack(b["keypoints"]),
+                         torch.stack(a["descriptors"]), torch.stack(b["descriptors"]), size, size, filter_threshold=0.1)
+
+    with torch.no_grad():
+        run()
+        run()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            run()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    return {"value": round(n_pairs * iters / dt, 2), "unit": "image-pairs/sec",
+            "sample": f"{iters} iterations of {n_pairs} VGA pairs, oracle tensors on cuda:0 (PyTorch-ROCm eager fp32)"}
+
+
 def rehearse_cpu(args):
     """Same control flow as main() around a dummy step, on gloo / CPU tensors (tests/test_host_cpu.py)."""
     rank, world, _ = sharding.init_from_env("gloo")
@@ -252,7 +283,9 @@ def main():
                        "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_bytes(),
+                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         # the committed PMC passes are of the default command; other shapes: not measured
+                         "traffic": pmc_traffic_bytes() if (args.workload == "c2" and imgs_per_launch == 64) else None,
                          "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of the "
                                          "default command (profiles/r01_pmc_summary.json); algorithmic per launch: "
                                          f"{imgs_per_launch * H * W * 4 / 1e6:.1f} MB image in + "
@@ -263,6 +296,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)
+            if args.workload == "c2":
+                out["cpu_baseline"]["same_gpu_torch_eager"] = torch_eager_same_gpu(dev)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

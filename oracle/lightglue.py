@@ -111,13 +111,14 @@ def filter_matches(scores: Tensor, th: float):
     keep mutual pairs with score > th.  Returns (m0 int64 [B,M], m1 int64 [B,N], s0, s1)."""
     b, m, n = scores.shape[0], scores.shape[1] - 1, scores.shape[2] - 1
     if m == 0 or n == 0:
-        return (torch.full((b, m), -1, dtype=torch.long), torch.full((b, n), -1, dtype=torch.long),
+        dv = scores.device
+        return (torch.full((b, m), -1, dtype=torch.long, device=dv), torch.full((b, n), -1, dtype=torch.long, device=dv),
                 scores.new_zeros((b, m)), scores.new_zeros((b, n)))
     inner = scores[:, :m, :n]
     best0, best1 = inner.max(2), inner.max(1)
     i0, i1 = best0.indices, best1.indices
-    mutual0 = torch.arange(m)[None] == i1.gather(1, i0)
-    mutual1 = torch.arange(n)[None] == i0.gather(1, i1)
+    mutual0 = torch.arange(m, device=i0.device)[None] == i1.gather(1, i0)
+    mutual1 = torch.arange(n, device=i0.device)[None] == i0.gather(1, i1)
     s0 = torch.where(mutual0, best0.values.exp(), best0.values.new_zeros(()))
     s1 = torch.where(mutual1, s0.gather(1, i1), s0.new_zeros(()))
     ok0 = mutual0 & (s0 > th)
