@@ -137,3 +137,183 @@ extern "C" int gfc_eval_matches_homography(const float* kp0, const float* kp1, c
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
+
+// ---- weighted DLT homography + corner error ("next" row rank 3) ---------------------------------------------
+// Replaces eval_homography_dlt (reference gluefactory/eval/utils.py:276-302): kornia's find_homography_dlt
+// (Hartley-normalised DLT, 2 rows per match, A^T diag(w) A, eigenvector of the smallest eigenvalue, de-normalise,
+// divide by H[2][2] + 1e-8) followed by homography_corner_error (gluefactory/geometry/homography.py:336-342).
+// One workgroup per pair; the 2n x 9 design matrix is never formed: each thread accumulates the 45 unique entries
+// of the 9x9 normal matrix in fp64, a cyclic Jacobi iteration in LDS (thread 0) finds the eigenvector.
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// block-wide sum of NV doubles per thread; result valid in every thread (via LDS)
+template <int NV>
+__device__ __forceinline__ void block_sum_f64(double* v, double* lds /* [4][NV] */, int tid) {
+  const int wave = tid >> 6;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) {
+    const double t = wave_sum_f64(v[q]);
+    if ((tid & 63) == 0) lds[wave * NV + q] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NV; ++q) v[q] = lds[q] + lds[NV + q] + lds[2 * NV + q] + lds[3 * NV + q];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(EM_THREADS) void dlt_kernel(const float* __restrict__ kp0, const float* __restrict__ kp1,
+                                                         const long long* __restrict__ m0,
+                                                         const float* __restrict__ sc0, const float* __restrict__ Hgt,
+                                                         const float* __restrict__ size0, int M, int N,
+                                                         float* __restrict__ Hout, float* __restrict__ err_out) {
+  __shared__ double red[4 * 45];
+  __shared__ double A[81], V[81];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* p0 = kp0 + (size_t)b * M * 2;
+  const float* p1 = kp1 + (size_t)b * N * 2;
+  const long long* mm = m0 + (size_t)b * M;
+  const float* ss = sc0 + (size_t)b * M;
+  // pass 1: count and centroids
+  double s5[5] = {0, 0, 0, 0, 0};
+  for (int i = tid; i < M; i += EM_THREADS) {
+    const long long j = mm[i];
+    if (j > -1 && j < N) {
+      s5[0] += 1.0; s5[1] += p0[2 * i]; s5[2] += p0[2 * i + 1]; s5[3] += p1[2 * j]; s5[4] += p1[2 * j + 1];
+    }
+  }
+  block_sum_f64<5>(s5, red, tid);
+  const double n = s5[0];
+  if (n < 4.0) {  // find_homography_dlt asserts >= 4 points; the caller turns that into H = inf (utils.py:291-292)
+    if (tid < 9) Hout[b * 9 + tid] = INFINITY;
+    if (tid == 0) err_out[b] = INFINITY;
+    return;
+  }
+  const double mx0 = s5[1] / n, my0 = s5[2] / n, mx1 = s5[3] / n, my1 = s5[4] / n;
+  // pass 2: mean distance to the centroid
+  double d2[2] = {0, 0};
+  for (int i = tid; i < M; i += EM_THREADS) {
+    const long long j = mm[i];
+    if (j > -1 && j < N) {
+      const double ax = p0[2 * i] - mx0, ay = p0[2 * i + 1] - my0, bx = p1[2 * j] - mx1, by = p1[2 * j + 1] - my1;
+      d2[0] += sqrt(ax * ax + ay * ay);
+      d2[1] += sqrt(bx * bx + by * by);
+    }
+  }
+  block_sum_f64<2>(d2, red, tid);
+  const double sc_a = 1.4142135623730951 / (d2[0] / n + 1e-8), sc_b = 1.4142135623730951 / (d2[1] / n + 1e-8);
+  // pass 3: normal matrix, upper triangle row-major (r <= c)
+  double acc[45];
+#pragma unroll
+  for (int q = 0; q < 45; ++q) acc[q] = 0.0;
+  for (int i = tid; i < M; i += EM_THREADS) {
+    const long long j = mm[i];
+    if (j > -1 && j < N) {
+      const double w = ss[i];
+      const double x1 = sc_a * (p0[2 * i] - mx0), y1 = sc_a * (p0[2 * i + 1] - my0);
+      const double x2 = sc_b * (p1[2 * j] - mx1), y2 = sc_b * (p1[2 * j + 1] - my1);
+      const double rx[9] = {0, 0, 0, -x1, -y1, -1.0, y2 * x1, y2 * y1, y2};
+      const double ry[9] = {x1, y1, 1.0, 0, 0, 0, -x2 * x1, -x2 * y1, -x2};
+      int q = 0;
+#pragma unroll
+      for (int r = 0; r < 9; ++r)
+#pragma unroll
+        for (int c = r; c < 9; ++c) acc[q++] += w * (rx[r] * rx[c] + ry[r] * ry[c]);
+    }
+  }
+  block_sum_f64<45>(acc, red, tid);
+  if (tid == 0) {
+    int q = 0;
+    for (int r = 0; r < 9; ++r)
+      for (int c = r; c < 9; ++c) { A[r * 9 + c] = acc[q]; A[c * 9 + r] = acc[q]; ++q; }
+    for (int r = 0; r < 81; ++r) V[r] = (r % 10 == 0) ? 1.0 : 0.0;
+    // cyclic Jacobi: A <- J^T A J, V <- V J
+    for (int sweep = 0; sweep < 60; ++sweep) {
+      double off = 0.0, dg = 0.0;
+      for (int r = 0; r < 9; ++r)
+        for (int c = 0; c < 9; ++c) { if (r == c) dg += A[r * 9 + c] * A[r * 9 + c]; else off += A[r * 9 + c] * A[r * 9 + c]; }
+      if (!(off > 1e-40 * dg)) break;  // also leaves on NaN
+      for (int p = 0; p < 8; ++p)
+        for (int r = p + 1; r < 9; ++r) {
+          const double apq = A[p * 9 + r];
+          if (fabs(apq) < 1e-300) continue;
+          const double theta = (A[r * 9 + r] - A[p * 9 + p]) / (2.0 * apq);
+          const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+          for (int k = 0; k < 9; ++k) {  // columns p, r
+            const double akp = A[k * 9 + p], akr = A[k * 9 + r];
+            A[k * 9 + p] = c * akp - s * akr;
+            A[k * 9 + r] = s * akp + c * akr;
+          }
+          for (int k = 0; k < 9; ++k) {  // rows p, r
+            const double apk = A[p * 9 + k], ark = A[r * 9 + k];
+            A[p * 9 + k] = c * apk - s * ark;
+            A[r * 9 + k] = s * apk + c * ark;
+          }
+          for (int k = 0; k < 9; ++k) {
+            const double vkp = V[k * 9 + p], vkr = V[k * 9 + r];
+            V[k * 9 + p] = c * vkp - s * vkr;
+            V[k * 9 + r] = s * vkp + c * vkr;
+          }
+        }
+    }
+    int best = 0;
+    for (int r = 1; r < 9; ++r)
+      if (A[r * 9 + r] < A[best * 9 + best]) best = r;
+    double h[9];
+    for (int r = 0; r < 9; ++r) h[r] = V[r * 9 + best];
+    // H = T2^-1 (Hn T1), T = [[s,0,-s mx],[0,s,-s my],[0,0,1]]
+    double g[9];
+    for (int r = 0; r < 3; ++r) {
+      g[r * 3 + 0] = h[r * 3 + 0] * sc_a;
+      g[r * 3 + 1] = h[r * 3 + 1] * sc_a;
+      g[r * 3 + 2] = -h[r * 3 + 0] * sc_a * mx0 - h[r * 3 + 1] * sc_a * my0 + h[r * 3 + 2];
+    }
+    double f[9];
+    for (int c = 0; c < 3; ++c) {
+      f[0 * 3 + c] = g[0 * 3 + c] / sc_b + mx1 * g[2 * 3 + c];
+      f[1 * 3 + c] = g[1 * 3 + c] / sc_b + my1 * g[2 * 3 + c];
+      f[2 * 3 + c] = g[2 * 3 + c];
+    }
+    const double den = f[8] + 1e-8;
+    float Hf[9];
+    bool finite = true;
+    for (int r = 0; r < 9; ++r) { Hf[r] = (float)(f[r] / den); finite = finite && isfinite(Hf[r]); }
+    float err = INFINITY;
+    if (finite) {
+      // homography_corner_error: corners (0,0) (W,0) (W,H) (0,H), plain division, mean distance, fp32 like the reference
+      const float Wd = size0[b * 2], Hd = size0[b * 2 + 1];
+      const float cx[4] = {0.f, Wd, Wd, 0.f}, cy[4] = {0.f, 0.f, Hd, Hd};
+      float Hg[9];
+      for (int r = 0; r < 9; ++r) Hg[r] = Hgt[b * 9 + r];
+      float sum = 0.f;
+      for (int k = 0; k < 4; ++k) {
+        float ax, ay, gx, gy;
+        warp_pt(Hf, cx[k], cy[k], 0.f, ax, ay);
+        warp_pt(Hg, cx[k], cy[k], 0.f, gx, gy);
+        sum += sqrtf((ax - gx) * (ax - gx) + (ay - gy) * (ay - gy));
+      }
+      err = sum / 4.f;
+      if (!isfinite(err)) err = INFINITY;
+    } else {
+      for (int r = 0; r < 9; ++r) Hf[r] = INFINITY;
+    }
+    for (int r = 0; r < 9; ++r) Hout[b * 9 + r] = Hf[r];
+    err_out[b] = err;
+  }
+}
+
+extern "C" int gfc_eval_homography_dlt(const float* kp0, const float* kp1, const int64_t* m0, const float* scores0,
+                                       const float* H_gt, const float* image_size0, int B, int M, int N, float* H_out,
+                                       float* err_out, void* stream) {
+  if (!kp0 || !kp1 || !m0 || !scores0 || !H_gt || !image_size0 || !H_out || !err_out || B <= 0 || M < 0 || N < 0)
+    return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(dlt_kernel, dim3(B), dim3(EM_THREADS), 0, (hipStream_t)stream, kp0, kp1, (const long long*)m0,
+                     scores0, H_gt, image_size0, M, N, H_out, err_out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

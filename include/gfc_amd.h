@@ -318,6 +318,16 @@ int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_
                                 const float* Hinv, int B, int M, int N, float pos_th, float neg_th, float* out,
                                 int64_t* gt_m0_out, void* stream);
 
+/* Weighted DLT homography from the predicted matches and its corner error ("next" row rank 3).  kp0 [B,M,2],
+ * kp1 [B,N,2], m0 [B,M] int64 (-1 = unmatched), scores0 [B,M] (the weights), H_gt [B,9] row-major, image_size0 [B,2]
+ * = (w, h) of view 0.  H_out [B,9]: normalised-DLT estimate divided by (H[2][2] + 1e-8), all +inf when a pair has
+ * fewer than 4 matches or the estimate is not finite; err_out [B]: mean distance of the 4 warped image corners to
+ * their ground-truth positions (+inf likewise).  Replaces eval_homography_dlt (gluefactory/eval/utils.py:276-302):
+ * kornia's find_homography_dlt (third-party, unpinned) + homography_corner_error (geometry/homography.py:336-342). */
+int gfc_eval_homography_dlt(const float* kp0, const float* kp1, const int64_t* m0, const float* scores0,
+                            const float* H_gt, const float* image_size0, int B, int M, int N, float* H_out,
+                            float* err_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,3 +86,67 @@ def eval_matches_homography(H_gt, kp0, kp1, m0):
     mask = ((m > -1) & (g >= -1)).float()
     res["gt_match_precision@3px"] = (((m == g) * mask).sum(1) / (1e-8 + mask.sum(1)))[0].item()
     return res
+
+
+# ---- weighted DLT homography + corner error -------------------------------------------
+# The reference calls kornia.geometry.homography.find_homography_dlt (third-party, `kornia >= 0.6.12`, unpinned in
+# pyproject.toml:31; ABSENT from this container and from /root/reference) at gluefactory/eval/utils.py:276-302.
+# PARITY UNPINNED for the solver: the function below restates kornia's published algorithm (Hartley-normalised DLT:
+# normalize_points -> 2 rows per correspondence -> A^T diag(w) A -> right singular vector of the smallest singular
+# value -> de-normalise -> divide by (H[2,2] + 1e-8)); it is pinned only by properties (exact correspondences
+# recover H_gt; the solution is the minimiser of the weighted algebraic residual) and, for the corner error it feeds,
+# by the reference-generated golden vectors of `homography_corner_error` above.
+
+
+def normalize_points(points, eps=1e-8):
+    """kornia.geometry.epipolar.normalize_points: centroid to origin, mean distance sqrt(2).  [B,N,2] -> pts, T [B,3,3]."""
+    mean = points.mean(1, keepdim=True)
+    scale = (points - mean).norm(dim=-1, p=2).mean(-1)
+    scale = (2.0 ** 0.5) / (scale + eps)
+    b = points.shape[0]
+    T = torch.zeros((b, 3, 3), dtype=points.dtype)
+    T[:, 0, 0] = scale
+    T[:, 1, 1] = scale
+    T[:, 0, 2] = -scale * mean[:, 0, 0]
+    T[:, 1, 2] = -scale * mean[:, 0, 1]
+    T[:, 2, 2] = 1.0
+    pn = from_h(to_h(points) @ T.transpose(-1, -2))
+    return pn, T
+
+
+def find_homography_dlt(points1, points2, weights=None):
+    """Weighted normalised DLT, [B,N,2] x [B,N,2] (x [B,N]) -> H [B,3,3] with points2 ~ H points1.
+    Raises AssertionError for fewer than 4 correspondences (the caller maps that to H = inf, eval/utils.py:291-292)."""
+    assert points1.shape == points2.shape and points1.shape[1] >= 4
+    p1, T1 = normalize_points(points1)
+    p2, T2 = normalize_points(points2)
+    x1, y1 = p1[..., 0:1], p1[..., 1:2]
+    x2, y2 = p2[..., 0:1], p2[..., 1:2]
+    one, zero = torch.ones_like(x1), torch.zeros_like(x1)
+    ax = torch.cat([zero, zero, zero, -x1, -y1, -one, y2 * x1, y2 * y1, y2], -1)
+    ay = torch.cat([x1, y1, one, zero, zero, zero, -x2 * x1, -x2 * y1, -x2], -1)
+    A = torch.cat([ax, ay], -1).reshape(points1.shape[0], -1, 9)
+    if weights is None:
+        AtA = A.transpose(-2, -1) @ A
+    else:
+        w = weights.unsqueeze(-1).repeat(1, 1, 2).reshape(points1.shape[0], -1)
+        AtA = A.transpose(-2, -1) @ (w.unsqueeze(-1) * A)
+    _, _, Vh = torch.linalg.svd(AtA)
+    Hn = Vh[:, -1, :].reshape(-1, 3, 3)
+    H = torch.inverse(T2) @ (Hn @ T1)
+    return H / (H[..., -1:, -1:] + 1e-8)
+
+
+def eval_homography_dlt(H_gt, kp0, kp1, m0, scores0, image_size0):
+    """eval/utils.py:276-302 for one pair: matched points weighted by their matching scores -> H_dlt ->
+    mean corner distance to H_gt; inf when the estimate is not finite or there are fewer than 4 matches."""
+    valid = m0 > -1
+    pts0, pts1, sc = kp0[valid], kp1[m0[valid]], scores0[valid].to(kp0)
+    try:
+        H = find_homography_dlt(pts0[None], pts1[None], sc[None])[0]
+    except AssertionError:
+        H = torch.full((3, 3), float("inf"))
+    if not torch.isfinite(H).all():
+        return H, float("inf")
+    err = homography_corner_error(H, H_gt, image_size0)
+    return H, (float(err) if torch.isfinite(err) else float("inf"))

@@ -173,3 +173,95 @@ def test_end_to_end_synthetic_homography_eval(tmp_path):
         pred = {k: torch.from_numpy(v).cuda() for k, v in r.items() if k in keys}
         res = eval_utils.eval_matches_homography({"H_0to1": H.cuda()}, pred)
         assert res["num_matches"] > 150 and res["prec@3px"] > 0.95 and res["gt_match_precision@3px"] > 0.9, res
+        dlt = eval_utils.eval_homography_dlt({"H_0to1": H.cuda(), "view0": {"image_size": torch.tensor([320.0, 240.0]).cuda()}},
+                                             pred)
+        assert dlt["H_error_dlt"] < 3.0, dlt  # score-weighted DLT over all matches: a few pixels at the corners
+
+
+# ---- rank 3: weighted DLT homography + corner error ----------------------------------------------------------
+def _dlt_case(seed, n_pts, noise, outlier_frac=0.0, H=None):
+    g = torch.Generator().manual_seed(seed)
+    H = H_REAL if H is None else H
+    kp0 = torch.rand((n_pts, 2), generator=g) * torch.tensor([640.0, 480.0])
+    kp1_all = oeh.from_h(oeh.to_h(kp0) @ H.T) + noise * torch.randn((n_pts, 2), generator=g)
+    perm = torch.randperm(n_pts, generator=g)
+    kp1 = kp1_all[perm]                      # shuffled: matches are a real permutation
+    m0 = torch.argsort(perm)                 # kp1[m0[i]] is the partner of kp0[i]
+    drop = torch.rand(n_pts, generator=g) < 0.3
+    m0 = torch.where(drop, torch.full_like(m0, -1), m0)
+    n_out = int(outlier_frac * n_pts)
+    if n_out:
+        idx = torch.nonzero(m0 > -1).flatten()[:n_out]
+        m0[idx] = torch.randint(0, n_pts, (n_out,), generator=g)
+    sc = torch.rand(n_pts, generator=g) * 0.9 + 0.1
+    return H, kp0, kp1, m0, sc
+
+
+def test_oracle_dlt_properties():
+    """The kornia solver is absent (parity unpinned): the restatement is pinned by what defines it."""
+    size = torch.tensor([640.0, 480.0])
+    # exact correspondences recover H_gt, whatever the weights
+    for H in (H_REAL, H_REAL2, torch.tensor([[1.02, 0.03, 5.0], [-0.02, 0.98, -3.0], [1e-5, -2e-5, 1.0]])):
+        Hgt, kp0, kp1, m0, sc = _dlt_case(3, 80, 0.0, H=H)
+        Hd, err = oeh.eval_homography_dlt(Hgt, kp0, kp1, m0, sc, size)
+        assert err < 2e-2, err
+        assert torch.allclose(Hd, Hgt / Hgt[2, 2], rtol=2e-3, atol=2e-3)
+    # the estimate minimises the weighted algebraic residual over unit vectors: compare with a float64 eigen solve
+    Hgt, kp0, kp1, m0, sc = _dlt_case(5, 200, 1.0)
+    v = m0 > -1
+    p0, p1, w = kp0[v].double(), kp1[m0[v]].double(), sc[v].double()
+    pn0, T0 = oeh.normalize_points(p0[None])
+    pn1, T1 = oeh.normalize_points(p1[None])
+    x1, y1, x2, y2 = pn0[0, :, 0], pn0[0, :, 1], pn1[0, :, 0], pn1[0, :, 1]
+    o, z = torch.ones_like(x1), torch.zeros_like(x1)
+    ax = torch.stack([z, z, z, -x1, -y1, -o, y2 * x1, y2 * y1, y2], -1)
+    ay = torch.stack([x1, y1, o, z, z, z, -x2 * x1, -x2 * y1, -x2], -1)
+    AtA = (ax.T * w) @ ax + (ay.T * w) @ ay
+    evals, evecs = torch.linalg.eigh(AtA)
+    Hn = evecs[:, 0].reshape(3, 3)
+    Href = torch.inverse(T1[0]) @ Hn @ T0[0]
+    Href = Href / Href[2, 2]
+    Hd, _ = oeh.eval_homography_dlt(Hgt, kp0, kp1, m0, sc, size)
+    assert torch.allclose(Hd.double(), Href, rtol=5e-3, atol=5e-3)
+    # fewer than 4 matches -> inf (AssertionError path of eval/utils.py:291-292)
+    m_few = torch.full((80,), -1, dtype=torch.long)
+    m_few[:3] = torch.arange(3)
+    Hd, err = oeh.eval_homography_dlt(Hgt, kp0[:80], kp1[:80], m_few, sc[:80], size)
+    assert err == float("inf") and torch.isinf(Hd).all()
+
+
+@pytest.mark.gpu
+def test_dlt_gpu_vs_oracle():
+    from glue_factory_colon_amd import eval_utils
+
+    size = torch.tensor([640.0, 480.0])
+    cases = [_dlt_case(11, 300, 0.0), _dlt_case(12, 300, 0.7), _dlt_case(13, 300, 2.0, 0.05),
+             _dlt_case(14, 300, 0.5, H=H_REAL2)]
+    Hs = torch.stack([c[0] for c in cases])
+    kp0 = torch.stack([c[1] for c in cases])
+    kp1 = torch.stack([c[2] for c in cases])
+    m0 = torch.stack([c[3] for c in cases])
+    sc = torch.stack([c[4] for c in cases])
+    m0[3, :] = -1
+    m0[3, :3] = torch.arange(3)  # < 4 matches
+    Hd, err = eval_utils.homography_dlt(Hs.cuda(), kp0.cuda(), kp1.cuda(), m0.cuda(), sc.cuda(), size.repeat(4, 1).cuda())
+    Hd, err = Hd.cpu(), err.cpu()
+    for i in range(4):
+        Ho, eo = oeh.eval_homography_dlt(Hs[i], kp0[i], kp1[i], m0[i], sc[i], size)
+        if eo == float("inf"):
+            assert err[i] == float("inf") and torch.isinf(Hd[i]).all()
+            continue
+        # the oracle solves in fp32 (as kornia does), the kernel accumulates in fp64: agreement to fp32-solver accuracy
+        assert abs(float(err[i]) - eo) <= 2e-2 + 2e-3 * eo, (i, float(err[i]), eo)
+        assert torch.allclose(Hd[i], Ho, rtol=3e-3, atol=3e-3), (i, Hd[i], Ho)
+    assert float(err[0]) < 1e-2  # exact correspondences recover H_gt
+    # the drop-in signature, un-batched and batched
+    data = {"H_0to1": Hs[1].cuda(), "view0": {"image_size": size.cuda()}}
+    pred = {"keypoints0": kp0[1].cuda(), "keypoints1": kp1[1].cuda(), "matches0": m0[1].cuda(),
+            "matching_scores0": sc[1].cuda()}
+    r = eval_utils.eval_homography_dlt(data, pred)
+    assert abs(r["H_error_dlt"] - float(err[1])) < 1e-6
+    rb = eval_utils.eval_homography_dlt({"H_0to1": Hs.cuda(), "view0": {"image_size": size.repeat(4, 1).cuda()}},
+                                        {"keypoints0": kp0.cuda(), "keypoints1": kp1.cuda(), "matches0": m0.cuda(),
+                                         "matching_scores0": sc.cuda()})
+    assert rb["H_error_dlt"][3] == float("inf") and len(rb["H_error_dlt"]) == 4
