@@ -328,6 +328,17 @@ int gfc_eval_homography_dlt(const float* kp0, const float* kp1, const int64_t* m
                             const float* H_gt, const float* image_size0, int B, int M, int N, float* H_out,
                             float* err_out, void* stream);
 
+/* Image preprocessing ("next" row rank 1): [uint8 -> float /255 ->] antialiased bilinear resize, fused.
+ * src: src_is_u8_hwc != 0: B interleaved HxWxC byte images (bgr != 0 reverses the channel order, as read_image does
+ * after cv2.imread, utils/image.py:135-145), converted like numpy_image_to_torch (image.py:148-156); else B planar
+ * CxHxW fp32 images.  dst [B,C,OH,OW] fp32.  antialias != 0 and a down-scaling axis: Gaussian blur with
+ * sigma = max((in/out - 1)/2, 0.001) per axis, kernel size int(max(4 sigma, 3)) made odd, reflect border, then
+ * bilinear interpolation with torch's align_corners=False/True source-index rule.  Replaces the
+ * kornia.geometry.transform.resize call of ImagePreprocessor.__call__ (gluefactory/utils/image.py:33-47; kornia is
+ * third-party and unpinned).  GFC_ERR_UNSUPPORTED for blur kernels wider than 63 taps (down-scaling > ~30x). */
+int gfc_preprocess_resize(const void* src, int src_is_u8_hwc, int bgr, int B, int C, int H, int W, float* dst, int OH,
+                          int OW, int align_corners, int antialias, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

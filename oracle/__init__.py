@@ -15,4 +15,4 @@ vectors).  The reference publishes no tensor-level fixtures of its own (SURVEY.m
 Each function cites the reference file:line it restates (paths relative to the
 reference repository root).
 """
-from . import eval_homography, lightglue, superpoint  # noqa: F401
+from . import eval_homography, lightglue, preprocess, superpoint  # noqa: F401

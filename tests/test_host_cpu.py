@@ -165,6 +165,13 @@ def test_shard_partitions():
         assert sorted(sum(rr, [])) == list(range(n))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return str(so.getsockname()[1])
+
+
 def test_gather_records_world2_gloo(tmp_path):
     """The only collective of the path: one gather of fixed-size records, 2 ranks on gloo."""
     script = tmp_path / "w.py"
@@ -186,9 +193,10 @@ def test_gather_records_world2_gloo(tmp_path):
         "    print('GATHER_OK')\n"
         "else:\n"
         "    assert out is None\n")
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29517", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0 and "GATHER_OK" in r.stdout, r.stdout + r.stderr
 
@@ -235,7 +243,7 @@ def test_bench_multiprocess_plumbing_rehearsal():
     import json
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
            "--warmup", "1", "--pairs", "4", "--rehearse-cpu"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
