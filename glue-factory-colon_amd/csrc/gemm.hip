@@ -5,8 +5,8 @@
 // the 1x1 convolutions of the SuperPoint heads (superpoint_open.py:112-118, NHWC makes them
 // plain GEMMs) and, in batched form, einsum("bmd,bnd->bmn") (lightglue.py:285).
 //
-// Workgroup = 8 waves = 128x256 output tile (4 waves = 128x128 for narrow N), K stepped by 32 through
-// double-buffered LDS (row stride 36 floats: conflict-free ds_read_b128 of 4 consecutive k per lane).
+// Workgroup = 4 waves = 128x128 output tile (64x64 for small problems), K stepped by 16 (or 32) through
+// double-buffered LDS (row stride K tile + 4 floats: conflict-free ds_read_b128 of 4 consecutive k per lane).
 // Each wave owns a 64x64 sub-tile = 2x2 MFMA 32x32 tiles; per 8-deep k group it issues 4 LDS reads
 // and 16 v_mfma_f32_32x32x2_f32.  The next K tile is prefetched global->registers while the current
 // one is multiplied; one barrier per K tile.
@@ -14,8 +14,7 @@
 
 #include "common.h"
 
-#define GBK 32
-#define GLD (GBK + 4)
+#define GBK 32  // K granularity of the API (every variant's K tile divides it)
 
 struct GemmArgs {
   const float* A0;
@@ -35,18 +34,21 @@ struct GemmArgs {
 };
 
 // 2 x NW waves; every wave owns MT x MT MFMA tiles of 32x32.
-//   MT = 2, NW = 4: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup = 8 waves / CU)   large problems
-//   MT = 2, NW = 2: 128x128 tile, 256 threads,  72 KB LDS (2 workgroups / CU)             narrow N
-//   MT = 1, NW = 2:  64x64  tile, 256 threads,  36 KB LDS (4 workgroups / CU)             small M (batch 1..4):
+//   MT = 2, NW = 2, BK = 16: 128x128 tile, 256 threads, 41 KB LDS (3 workgroups / CU)    default for large problems
+//   MT = 2, NW = 4, BK = 32: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup / CU)    knob only
+//   MT = 2, NW = 2, BK = 32: 128x128 tile, 256 threads,  72 KB LDS (2 workgroups / CU)   knob only
+//   MT = 1, NW = 2, BK = 32:  64x64  tile, 256 threads,  36 KB LDS (4 workgroups / CU)   small M (batch 1..4):
 //                    4x the workgroups, so that a [2048, 256] GEMM still covers the chip
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
 // underneath the MFMAs of the current one.
-template <int NW, int MT>
-__global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
+template <int NW, int MT, int BK>
+__global__ __launch_bounds__(128 * NW, BK == 16 ? 3 : 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int T = 128 * NW;        // threads
   constexpr int GBM = 64 * MT;       // tile height (2 waves)
   constexpr int BN = 32 * MT * NW;   // tile width
-  constexpr int RPP = T / 8;         // rows staged per pass
+  constexpr int GLD = BK + 4;        // LDS row stride (floats)
+  constexpr int C4 = BK / 4;         // float4 per staged row
+  constexpr int RPP = T / C4;        // rows staged per pass
   constexpr int NA = GBM / RPP;      // float4 of A per thread per K tile
   constexpr int NB = BN / RPP;       // float4 of W per thread per K tile
   constexpr int TILE = (GBM + BN) * GLD;
@@ -62,10 +64,10 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
   const float* A1 = g.A1 ? g.A1 + z * g.strideA : nullptr;
   const float* W = g.W + z * g.strideW;
   float* Y = g.Y + z * g.strideY;
-  const int ktiles = (g.K0 + g.K1) / GBK;
+  const int ktiles = (g.K0 + g.K1) / BK;
 
-  const int s_c4 = (tid & 7) * 4;
-  const int s_r0 = tid >> 3;
+  const int s_c4 = (tid % C4) * 4;
+  const int s_r0 = tid / C4;
   // staged rows (clamped; out-of-range rows are never stored by the epilogue).  Named registers and
   // wave-uniform pointer selection: arrays / per-branch loads were demoted to private memory by hipcc.
   const int ar0 = min(m0 + s_r0, g.M - 1), ar1 = min(m0 + s_r0 + RPP, g.M - 1);
@@ -74,23 +76,23 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
   const float* w1p = W + (size_t)min(n0 + s_r0 + RPP, g.N - 1) * g.ldw + s_c4;
   const float* w2p = W + (size_t)min(n0 + s_r0 + 2 * RPP, g.N - 1) * g.ldw + s_c4;
   const float* w3p = W + (size_t)min(n0 + s_r0 + 3 * RPP, g.N - 1) * g.ldw + s_c4;
-  static_assert((NB == 2 || NB == 4) && (NA == 2 || NA == 4), "staging layout");
+  static_assert((NB == 1 || NB == 2 || NB == 4) && (NA == 1 || NA == 2 || NA == 4), "staging layout");
   float4 areg0, areg1, areg2, areg3, wreg0, wreg1, wreg2, wreg3;
-  areg2 = areg3 = wreg2 = wreg3 = make_float4(0.f, 0.f, 0.f, 0.f);
+  areg1 = wreg1 = areg2 = areg3 = wreg2 = wreg3 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define GEMM_LOAD_TILE(kt)                                                                           \
   do {                                                                                               \
-    const int k0_ = (kt) * GBK;                                                                      \
+    const int k0_ = (kt) * BK;                                                                       \
     const bool first_ = k0_ < g.K0;                                                                  \
     const float* ab_ = (first_ ? A0 : A1) + (first_ ? k0_ : k0_ - g.K0) + s_c4;                      \
     const size_t ld_ = first_ ? g.lda0 : g.lda1;                                                     \
     areg0 = *reinterpret_cast<const float4*>(ab_ + ar0 * ld_);                                       \
-    areg1 = *reinterpret_cast<const float4*>(ab_ + ar1 * ld_);                                       \
+    if constexpr (NA >= 2) areg1 = *reinterpret_cast<const float4*>(ab_ + ar1 * ld_);                \
     if constexpr (NA == 4) {                                                                         \
       areg2 = *reinterpret_cast<const float4*>(ab_ + ar2 * ld_);                                     \
       areg3 = *reinterpret_cast<const float4*>(ab_ + ar3 * ld_);                                     \
     }                                                                                                \
     wreg0 = *reinterpret_cast<const float4*>(w0p + k0_);                                             \
-    wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                                             \
+    if constexpr (NB >= 2) wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                      \
     if constexpr (NB == 4) {                                                                         \
       wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                                           \
       wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                                           \
@@ -101,13 +103,13 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
     float* as_ = smem + (buf_) * TILE + s_r0 * GLD + s_c4;                                           \
     float* bs_ = as_ + GBM * GLD;                                                                    \
     *reinterpret_cast<float4*>(as_) = areg0;                                                         \
-    *reinterpret_cast<float4*>(as_ + RPP * GLD) = areg1;                                             \
+    if constexpr (NA >= 2) *reinterpret_cast<float4*>(as_ + RPP * GLD) = areg1;                      \
     if constexpr (NA == 4) {                                                                         \
       *reinterpret_cast<float4*>(as_ + 2 * RPP * GLD) = areg2;                                       \
       *reinterpret_cast<float4*>(as_ + 3 * RPP * GLD) = areg3;                                       \
     }                                                                                                \
     *reinterpret_cast<float4*>(bs_) = wreg0;                                                         \
-    *reinterpret_cast<float4*>(bs_ + RPP * GLD) = wreg1;                                             \
+    if constexpr (NB >= 2) *reinterpret_cast<float4*>(bs_ + RPP * GLD) = wreg1;                      \
     if constexpr (NB == 4) {                                                                         \
       *reinterpret_cast<float4*>(bs_ + 2 * RPP * GLD) = wreg2;                                       \
       *reinterpret_cast<float4*>(bs_ + 3 * RPP * GLD) = wreg3;                                       \
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
     const float* ap = smem + (kt & 1) * TILE + a_off;
     const float* bp = smem + (kt & 1) * TILE + b_off;
 #pragma unroll
-    for (int gk = 0; gk < 4; ++gk) {
+    for (int gk = 0; gk < BK / 8; ++gk) {
       float4 af[MT], bf[MT];
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -207,12 +209,16 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
   const int rd = colb & 63;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    __syncthreads();  // previous round's reads (or the K loop's) are complete
+    // The patch is private to the wave and the K loop ended on a workgroup barrier: LDS operations of one wave
+    // complete in order, so only the compiler has to be kept from reordering across the transpose.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int nt = 0; nt < MT; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int i = 0; i < 32 / RPS; ++i) {
       const int lr = er + RPS * i;
@@ -249,36 +255,39 @@ __global__ __launch_bounds__(128 * NW, 2) void gemm_nt_kernel(GemmArgs g) {
   }
 }
 
-template <int NW, int MT>
+template <int NW, int MT, int BK>
 static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   constexpr int BM = 64 * MT, BN = 32 * MT * NW;
-  const size_t lds = (size_t)2 * (BM + BN) * GLD * sizeof(float);
+  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW, MT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW, MT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
     attr_set = true;
   }
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT>), grid, dim3(128 * NW), lds, st, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK>), grid, dim3(128 * NW), lds, st, g);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
 
 static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
-  // tuning knob (tools/bench_kernels.py): GFC_GEMM_TILE=1 (128x256) | 2 (128x128) | 3 (64x64)
+  // tuning knob (tools/bench_kernels.py): GFC_GEMM_TILE=1 (128x256) | 2 (128x128) | 3 (64x64) | 4 (128x128, K tile 16)
+  // | 5 (64x64, K tile 16)
   static const int forced = [] { const char* e = getenv("GFC_GEMM_TILE"); return e ? atoi(e) : 0; }();
   auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
   int choice = forced;
   if (!choice) {
-    // largest tile that still gives every CU work; the 128-wide variants need N to fill them
-    if (g.N % 256 == 0 && tiles(128, 256) >= 256) choice = 1;
-    else if (tiles(128, 128) >= 256) choice = 2;
-    else choice = 3;
+    // 128x128 tiles with a 16-deep K tile (41 KB LDS, three workgroups per CU: while one drains its stores two
+    // others keep the MFMA pipe busy; +5..11 % over the 32-deep variants at M = 65536) once there are three per CU,
+    // else 64x64 tiles so that small-batch GEMMs still cover the chip
+    choice = tiles(128, 128) >= 768 ? 4 : 3;
   }
-  if (choice == 1) return launch_gemm_t<4, 2>(g, batch, st);
-  if (choice == 2) return launch_gemm_t<2, 2>(g, batch, st);
-  return launch_gemm_t<2, 1>(g, batch, st);
+  if (choice == 1) return launch_gemm_t<4, 2, 32>(g, batch, st);
+  if (choice == 2) return launch_gemm_t<2, 2, 32>(g, batch, st);
+  if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 41 KB LDS: 3 workgroups / CU
+  if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
+  return launch_gemm_t<2, 1, 32>(g, batch, st);
 }
 
 extern "C" int gfc_linear(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W, int ldw,

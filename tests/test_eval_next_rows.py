@@ -175,7 +175,11 @@ def test_end_to_end_synthetic_homography_eval(tmp_path):
         assert res["num_matches"] > 150 and res["prec@3px"] > 0.95 and res["gt_match_precision@3px"] > 0.9, res
         dlt = eval_utils.eval_homography_dlt({"H_0to1": H.cuda(), "view0": {"image_size": torch.tensor([320.0, 240.0]).cuda()}},
                                              pred)
-        assert dlt["H_error_dlt"] < 3.0, dlt  # score-weighted DLT over all matches: a few pixels at the corners
+        # least squares over ALL matches (no RANSAC): a few wrong matches move the corners by pixels; what is
+        # checked is agreement with the oracle on the same predictions
+        _, eo = oeh.eval_homography_dlt(H, pred["keypoints0"].cpu(), pred["keypoints1"].cpu(), pred["matches0"].cpu(),
+                                        pred["matching_scores0"].cpu(), torch.tensor([320.0, 240.0]))
+        assert abs(dlt["H_error_dlt"] - eo) <= 0.05 + 0.01 * eo, (dlt, eo)
 
 
 # ---- rank 3: weighted DLT homography + corner error ----------------------------------------------------------
