@@ -11,12 +11,13 @@
 // in LDS and prefetched through registers while the MFMAs of the current step run.
 // Each lane reads 4 consecutive k with one ds_read_b128; MFMA s of a group pairs k = 4h+s of
 // both lane halves (any k order is a valid dot product as long as A and B agree).
+#include <stdlib.h>
+
 #include "common.h"
 
 #define CT 16              // output tile edge (pixels)
 #define CH (CT + 2)        // halo tile edge
-#define CKC 32             // channels per chunk
-#define CLD (CKC + 4)      // LDS row stride in floats (bank-conflict padding, keeps 16B alignment)
+#define CKC 32             // channel granularity of the API (every variant's chunk divides it)
 #define CNB 64             // output channels per workgroup
 
 __global__ void pack_conv3x3_kernel(const float* __restrict__ w, float* __restrict__ out, int cout, int cin) {
@@ -110,8 +111,13 @@ struct ConvArgs {
 // read from HBM (superpoint_open.py:100-103: backbone.0.0 feeding backbone.0.1).  This removes the
 // largest activation of the network (B*H*W*64 floats written and read back) and one launch.
 #define CIM (CT + 4)
-template <bool POOL, bool STEM>
-__global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
+// KC = channels per chunk: 32 (65 KB LDS, 2 workgroups / CU) or 16 (36 KB, 3 workgroups / CU)
+template <bool POOL, bool STEM, int KC>
+__global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(ConvArgs a) {
+  constexpr int CLD = KC + 4;                        // LDS row stride in floats (bank-conflict padding, 16B aligned)
+  constexpr int C4 = KC / 4;                         // float4 per staged row
+  constexpr int NI = (CH * CH * C4 + 255) / 256;     // input float4 per thread per chunk
+  constexpr int NWR = CNB * C4 / 256;                // weight float4 per thread per step (1 or 2)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* in_s = smem;                   // [CH*CH][CLD]
   float* w_s = smem + CH * CH * CLD;    // [2][CNB][CLD]
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   const int nb = blockIdx.y;
   const int x0 = tx * CT, y0 = ty * CT;
   const int cin = a.cin;
-  const int nchunks = cin / CKC;
+  const int nchunks = cin / KC;
   const int nsteps = nchunks * 9;
 
   const float* xin = a.x + (size_t)b * a.H * a.W * cin;
@@ -140,34 +146,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
   // ---- staging (register prefetch).  Macros, not lambdas: the prefetch registers must stay in
   // VGPRs (a by-reference lambda capture demoted them to a private-memory array). ----
   float4 wreg0, wreg1;
-  float4 ireg[11];
-  const int st_co = tid >> 3, st_c4 = (tid & 7) * 4;  // weight rows st_co, st_co + 32
+  float4 ireg[NI];
+  const int st_co = tid / C4, st_c4 = (tid % C4) * 4;  // weight rows st_co (, st_co + 32)
+  wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define CONV_LOAD_W(step_)                                                                  \
   do {                                                                                      \
     const int ch_ = (step_) / 9, tp_ = (step_) - ch_ * 9;                                   \
-    const float* src_ = wbase + (size_t)tp_ * a.cout * cin + ch_ * CKC + st_c4;             \
+    const float* src_ = wbase + (size_t)tp_ * a.cout * cin + ch_ * KC + st_c4;              \
     wreg0 = *reinterpret_cast<const float4*>(src_ + (size_t)st_co * cin);                   \
-    wreg1 = *reinterpret_cast<const float4*>(src_ + (size_t)(st_co + 32) * cin);            \
+    if constexpr (NWR == 2) wreg1 = *reinterpret_cast<const float4*>(src_ + (size_t)(st_co + 32) * cin); \
   } while (0)
 #define CONV_STORE_W(buf_)                                                                  \
   do {                                                                                      \
     float* dst_ = w_s + (buf_) * CNB * CLD + st_co * CLD + st_c4;                           \
     *reinterpret_cast<float4*>(dst_) = wreg0;                                               \
-    *reinterpret_cast<float4*>(dst_ + 32 * CLD) = wreg1;                                    \
+    if constexpr (NWR == 2) *reinterpret_cast<float4*>(dst_ + 32 * CLD) = wreg1;            \
   } while (0)
 #define CONV_LOAD_IN(chunk_)                                                                \
-  _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                       \
     const int idx_ = tid + 256 * i_;                                                        \
-    const int p_ = idx_ >> 3;                                                               \
+    const int p_ = idx_ / C4;                                                               \
     const int gy_ = y0 - 1 + p_ / CH, gx_ = x0 - 1 + p_ % CH;                               \
     float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
-    if (idx_ < CH * CH * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W)               \
-      v_ = *reinterpret_cast<const float4*>(xin + ((size_t)gy_ * a.W + gx_) * cin + (chunk_) * CKC + st_c4); \
+    if (idx_ < CH * CH * C4 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W)              \
+      v_ = *reinterpret_cast<const float4*>(xin + ((size_t)gy_ * a.W + gx_) * cin + (chunk_) * KC + st_c4); \
     ireg[i_] = v_;                                                                          \
   }
 #define CONV_FILL_IN(chunk_)                                                                \
   {                                                                                         \
-    const int c0_ = (chunk_) * CKC + st_c4;                                                 \
+    const int c0_ = (chunk_) * KC + st_c4;                                                  \
     float4 wv_[9];                                                                          \
     _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                        \
         wv_[t_] = *reinterpret_cast<const float4*>(a.w1 + t_ * 64 + c0_);                   \
@@ -177,13 +184,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
       s1_ = *reinterpret_cast<const float4*>(a.s1 + c0_);                                   \
       t1_ = *reinterpret_cast<const float4*>(a.t1 + c0_);                                   \
     }                                                                                       \
-    _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                     \
       const int idx_ = tid + 256 * i_;                                                      \
-      const int p_ = idx_ >> 3;                                                             \
+      const int p_ = idx_ / C4;                                                             \
       const int py_ = p_ / CH, px_ = p_ % CH;                                               \
       const int gy_ = y0 - 1 + py_, gx_ = x0 - 1 + px_;                                     \
       float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
-      if (idx_ < CH * CH * 8 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W) {           \
+      if (idx_ < CH * CH * C4 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W) {          \
         _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) {                                  \
           const float f_ = img_s[(py_ + t_ / 3) * CIM + px_ + t_ % 3];                      \
           v_.x = fmaf(f_, wv_[t_].x, v_.x);                                                 \
@@ -200,9 +207,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     }                                                                                       \
   }
 #define CONV_STORE_IN()                                                                     \
-  _Pragma("unroll") for (int i_ = 0; i_ < 11; ++i_) {                                       \
+  _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                       \
     const int idx_ = tid + 256 * i_;                                                        \
-    if (idx_ < CH * CH * 8) *reinterpret_cast<float4*>(in_s + (idx_ >> 3) * CLD + st_c4) = ireg[i_]; \
+    if (idx_ < CH * CH * C4) *reinterpret_cast<float4*>(in_s + (idx_ / C4) * CLD + st_c4) = ireg[i_]; \
   }
 
   // this lane's two pixel rows in the halo image (tap (0,0) corner), and weight rows
@@ -253,21 +260,20 @@ __global__ __launch_bounds__(256, 2) void conv3x3_mfma_kernel(ConvArgs a) {
     const float* ap = in_s + (dy * CH + dx) * CLD;
     const float* bp = w_s + (step & 1) * CNB * CLD;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
+    for (int g = 0; g < KC / 8; ++g) {
       float4 af[2], bf[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const float4*>(ap + a_off[mt] + 8 * g);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const float4*>(bp + b_off[nt] + 8 * g);
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
-          acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
-          acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
-          acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
-        }
+      // k-major order: consecutive MFMAs go to different accumulators (same per-accumulator order of the 4 k pairs)
+#define CONV_MFMA4(c_)                                                   \
+  acc[0][0] = mfma32(af[0].c_, bf[0].c_, acc[0][0]);                     \
+  acc[0][1] = mfma32(af[0].c_, bf[1].c_, acc[0][1]);                     \
+  acc[1][0] = mfma32(af[1].c_, bf[0].c_, acc[1][0]);                     \
+  acc[1][1] = mfma32(af[1].c_, bf[1].c_, acc[1][1]);
+      CONV_MFMA4(x) CONV_MFMA4(y) CONV_MFMA4(z) CONV_MFMA4(w)
+#undef CONV_MFMA4
     }
     if (has_next) CONV_STORE_W((step + 1) & 1);
     if (new_chunk) {
@@ -383,26 +389,36 @@ extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* b
   return launch_conv(a, pool != 0, false, st);
 }
 
+template <bool POOL, bool STEM, int KC>
+static int launch_conv_t(const ConvArgs& a, dim3 grid, hipStream_t st) {
+  const size_t lds = (size_t)(CH * CH * (KC + 4) + 2 * CNB * (KC + 4) + (STEM ? CIM * CIM : 0)) * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<POOL, STEM, KC>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<POOL, STEM, KC>), grid, dim3(256), lds, st, a);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
 static int launch_conv(ConvArgs a, bool pool, bool stem, hipStream_t st) {
   a.tiles_x = (a.W + CT - 1) / CT;
   a.tiles_y = (a.H + CT - 1) / CT;
   dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), a.cout / CNB);
-  const size_t lds = (size_t)(CH * CH * CLD + 2 * CNB * CLD + (stem ? CIM * CIM : 0)) * sizeof(float);
-  if (stem) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<true, true>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<true, true>), grid, dim3(256), lds, st, a);
-  } else if (pool) {
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<true, false>), grid, dim3(256), lds, st, a);
-  } else {
-    hipLaunchKernelGGL((conv3x3_mfma_kernel<false, false>), grid, dim3(256), lds, st, a);
+  // channels per LDS chunk: 16 (36 KB, three workgroups per CU) is 1-2 % faster for the pooled layers (stem: 5.64 ->
+  // 5.55 ms at 32 images), 32 for the un-pooled ones; GFC_CONV_KC=32|16 forces one (tools/bench_kernels.py)
+  static const int forced = [] { const char* e = getenv("GFC_CONV_KC"); return e ? atoi(e) : 0; }();
+  const int kc = forced ? forced : (pool ? 16 : 32);
+  if (kc == 16) {
+    if (stem) return launch_conv_t<true, true, 16>(a, grid, st);
+    if (pool) return launch_conv_t<true, false, 16>(a, grid, st);
+    return launch_conv_t<false, false, 16>(a, grid, st);
   }
-  GFC_LAUNCH_CHECK();
-  return GFC_OK;
+  if (stem) return launch_conv_t<true, true, 32>(a, grid, st);
+  if (pool) return launch_conv_t<true, false, 32>(a, grid, st);
+  return launch_conv_t<false, false, 32>(a, grid, st);
 }
 
 // conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in one launch: gray image [B,H,W] -> [B,H/2,W/2,64].

@@ -42,7 +42,7 @@ struct GemmArgs {
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
 // underneath the MFMAs of the current one.
 template <int NW, int MT, int BK>
-__global__ __launch_bounds__(128 * NW, BK == 16 ? 3 : 2) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void gemm_nt_kernel(GemmArgs g) {
   constexpr int T = 128 * NW;        // threads
   constexpr int GBM = 64 * MT;       // tile height (2 waves)
   constexpr int BN = 32 * MT * NW;   // tile width
@@ -258,7 +258,9 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? 3 : 2) void gemm_nt_kernel(Gem
 template <int NW, int MT, int BK>
 static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   constexpr int BM = 64 * MT, BN = 32 * MT * NW;
-  const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+  // K-loop buffers, or the per-wave transpose patches of the rotary / residual epilogue if those are larger
+  constexpr size_t kloop = (size_t)2 * (BM + BN) * (BK + 4), patches = (size_t)2 * NW * 32 * (32 * MT + 4);
+  const size_t lds = (kloop > patches ? kloop : patches) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW, MT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -287,6 +289,7 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   if (choice == 2) return launch_gemm_t<2, 2, 32>(g, batch, st);
   if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 41 KB LDS: 3 workgroups / CU
   if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
+  if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);  // 128x256, 61 KB LDS: 2 workgroups of 8 waves / CU
   return launch_gemm_t<2, 1, 32>(g, batch, st);
 }
 
