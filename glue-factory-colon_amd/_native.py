@@ -10,7 +10,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libgfc_amd.so")
+# GFC_AMD_LIB: another build of the same library (same-box A/B of kernel variants: tools/ab_build.sh)
+LIB_PATH = os.environ.get("GFC_AMD_LIB") or os.path.join(_PKG, "libgfc_amd.so")
 GFC_LG_MAX_LAYERS = 16
 
 STATUS = {0: "GFC_OK", 1: "GFC_ERR_INVALID", 2: "GFC_ERR_WORKSPACE", 3: "GFC_ERR_UNSUPPORTED", 4: "GFC_ERR_LAUNCH"}

@@ -111,9 +111,14 @@ struct ConvArgs {
 // read from HBM (superpoint_open.py:100-103: backbone.0.0 feeding backbone.0.1).  This removes the
 // largest activation of the network (B*H*W*64 floats written and read back) and one launch.
 #define CIM (CT + 4)
+#ifndef CONV_LOAD_TAP
+#define CONV_LOAD_TAP 2   // tap at which the next input chunk's global loads are issued (stored after tap 8)
+#endif
 // KC = channels per chunk: 32 (65 KB LDS, 2 workgroups / CU) or 16 (36 KB, 3 workgroups / CU)
-template <bool POOL, bool STEM, int KC>
-__global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(ConvArgs a) {
+// PERSIST = workgroups walk several work items with the next item's operands prefetched (see below); without it the
+// grid has one workgroup per item and the hand-over code (and its registers) is compiled out.
+template <bool POOL, bool STEM, int KC, bool PERSIST>
+__global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_mfma_kernel(ConvArgs a) {
   constexpr int CLD = KC + 4;                        // LDS row stride in floats (bank-conflict padding, 16B aligned)
   constexpr int C4 = KC / 4;                         // float4 per staged row
   constexpr int NI = (CH * CH * C4 + 255) / 256;     // input float4 per thread per chunk
@@ -129,19 +134,35 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
   const int l31 = lane & 31;
   const int h = lane >> 5;
 
-  int bid = blockIdx.x;
-  const int tx = bid % a.tiles_x;
-  bid /= a.tiles_x;
-  const int ty = bid % a.tiles_y;
-  const int b = bid / a.tiles_y;
-  const int nb = blockIdx.y;
-  const int x0 = tx * CT, y0 = ty * CT;
+  // Persistent workgroups: work item w = tile + ntiles * (output-channel block); a workgroup walks w = blockIdx.x,
+  // blockIdx.x + gridDim.x, ...  While the last K step of one item runs, the halo tile and first weight slice of
+  // the next item are already on their way (global -> registers), so neither the load latency of the prologue nor the
+  // store drain of the epilogue leaves the MFMA pipe idle (in-kernel stamps: they were 16 % + 13 % of a workgroup's
+  // life at 64 -> 64 channels).
   const int cin = a.cin;
   const int nchunks = cin / KC;
   const int nsteps = nchunks * 9;
-
-  const float* xin = a.x + (size_t)b * a.H * a.W * cin;
-  const float* wbase = a.w + (size_t)nb * CNB * cin;  // + tap*cout*cin + co*cin + chunk*32
+  const int ntiles = a.tiles_x * a.tiles_y * a.B;
+  const int nitems = ntiles * (a.cout / CNB);
+  int item = blockIdx.x;
+  // current item (x0, y0, b, nb, xin, wbase) and the next one (n*)
+  int x0, y0, b, nb, nx0 = 0, ny0 = 0, nb_b = 0, nnb = 0;
+  const float* xin;
+  const float* wbase;
+  const float* nxin = nullptr;
+  const float* nwbase = nullptr;
+#define CONV_DECODE(w_, x0_, y0_, b_, nb_, xin_, wbase_)                                    \
+  do {                                                                                      \
+    int t_ = (w_) % ntiles;                                                                 \
+    nb_ = (w_) / ntiles;                                                                    \
+    x0_ = (t_ % a.tiles_x) * CT;                                                            \
+    t_ /= a.tiles_x;                                                                        \
+    y0_ = (t_ % a.tiles_y) * CT;                                                            \
+    b_ = t_ / a.tiles_y;                                                                    \
+    xin_ = a.x + (size_t)b_ * a.H * a.W * (STEM ? 1 : cin);                                 \
+    wbase_ = a.w + (size_t)nb_ * CNB * cin; /* + tap*cout*cin + co*cin + chunk*KC */         \
+  } while (0)
+  CONV_DECODE(item, x0, y0, b, nb, xin, wbase);
 
   // ---- staging (register prefetch).  Macros, not lambdas: the prefetch registers must stay in
   // VGPRs (a by-reference lambda capture demoted them to a private-memory array). ----
@@ -149,10 +170,10 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
   float4 ireg[NI];
   const int st_co = tid / C4, st_c4 = (tid % C4) * 4;  // weight rows st_co (, st_co + 32)
   wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define CONV_LOAD_W(step_)                                                                  \
+#define CONV_LOAD_W(base_, step_)                                                               \
   do {                                                                                      \
     const int ch_ = (step_) / 9, tp_ = (step_) - ch_ * 9;                                   \
-    const float* src_ = wbase + (size_t)tp_ * a.cout * cin + ch_ * KC + st_c4;              \
+    const float* src_ = (base_) + (size_t)tp_ * a.cout * cin + ch_ * KC + st_c4;            \
     wreg0 = *reinterpret_cast<const float4*>(src_ + (size_t)st_co * cin);                   \
     if constexpr (NWR == 2) wreg1 = *reinterpret_cast<const float4*>(src_ + (size_t)(st_co + 32) * cin); \
   } while (0)
@@ -162,17 +183,17 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
     *reinterpret_cast<float4*>(dst_) = wreg0;                                               \
     if constexpr (NWR == 2) *reinterpret_cast<float4*>(dst_ + 32 * CLD) = wreg1;            \
   } while (0)
-#define CONV_LOAD_IN(chunk_)                                                                \
+#define CONV_LOAD_IN(chunk_, xin_, y0_, x0_)                                                \
   _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                       \
     const int idx_ = tid + 256 * i_;                                                        \
     const int p_ = idx_ / C4;                                                               \
-    const int gy_ = y0 - 1 + p_ / CH, gx_ = x0 - 1 + p_ % CH;                               \
+    const int gy_ = (y0_) - 1 + p_ / CH, gx_ = (x0_) - 1 + p_ % CH;                         \
     float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
     if (idx_ < CH * CH * C4 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W)              \
-      v_ = *reinterpret_cast<const float4*>(xin + ((size_t)gy_ * a.W + gx_) * cin + (chunk_) * KC + st_c4); \
+      v_ = *reinterpret_cast<const float4*>((xin_) + ((size_t)gy_ * a.W + gx_) * cin + (chunk_) * KC + st_c4); \
     ireg[i_] = v_;                                                                          \
   }
-#define CONV_FILL_IN(chunk_)                                                                \
+#define CONV_FILL_IN(chunk_, y0_, x0_)                                                      \
   {                                                                                         \
     const int c0_ = (chunk_) * KC + st_c4;                                                  \
     float4 wv_[9];                                                                          \
@@ -188,7 +209,7 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
       const int idx_ = tid + 256 * i_;                                                      \
       const int p_ = idx_ / C4;                                                             \
       const int py_ = p_ / CH, px_ = p_ % CH;                                               \
-      const int gy_ = y0 - 1 + py_, gx_ = x0 - 1 + px_;                                     \
+      const int gy_ = (y0_) - 1 + py_, gx_ = (x0_) - 1 + px_;                               \
       float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                          \
       if (idx_ < CH * CH * C4 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W) {          \
         _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_) {                                  \
@@ -223,37 +244,70 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
   for (int nt = 0; nt < 2; ++nt) b_off[nt] = (nt * 32 + l31) * CLD + 4 * h;
 
   f32x16 acc[2][2];
+  // STEM: 20x20 image patch around the tile (zero outside the image = conv1a's own zero padding), 2 floats / thread
+  float ip0 = 0.f, ip1 = 0.f;
+#define CONV_LOAD_IMG(img_, y0_, x0_)                                                       \
+  do {                                                                                      \
+    const int i0_ = tid, i1_ = tid + 256;                                                   \
+    const int gy0_ = (y0_) - 2 + i0_ / CIM, gx0_ = (x0_) - 2 + i0_ % CIM;                   \
+    const int gy1_ = (y0_) - 2 + i1_ / CIM, gx1_ = (x0_) - 2 + i1_ % CIM;                   \
+    ip0 = (gy0_ >= 0 && gy0_ < a.H && gx0_ >= 0 && gx0_ < a.W) ? (img_)[(size_t)gy0_ * a.W + gx0_] : 0.f; \
+    ip1 = (i1_ < CIM * CIM && gy1_ >= 0 && gy1_ < a.H && gx1_ >= 0 && gx1_ < a.W)          \
+              ? (img_)[(size_t)gy1_ * a.W + gx1_] : 0.f;                                    \
+  } while (0)
+#define CONV_STORE_IMG()                                                                    \
+  do {                                                                                      \
+    img_s[tid] = ip0;                                                                       \
+    if (tid + 256 < CIM * CIM) img_s[tid + 256] = ip1;                                      \
+  } while (0)
+
+  if constexpr (STEM) {
+    CONV_LOAD_IMG(xin, y0, x0);
+    CONV_STORE_IMG();
+    __syncthreads();
+    CONV_FILL_IN(0, y0, x0);
+  } else {
+    CONV_LOAD_IN(0, xin, y0, x0);
+  }
+  CONV_LOAD_W(wbase, 0);
+
+  while (true) {
+  CONV_STORE_IN();
+  CONV_STORE_W(0);
+  __syncthreads();
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
+  const int next_item = item + gridDim.x;
+  const bool more = PERSIST && next_item < nitems;
+  if (more) CONV_DECODE(next_item, nx0, ny0, nb_b, nnb, nxin, nwbase);
   if constexpr (STEM) {
-    // 20x20 image patch around the tile (zero outside the image = conv1a's own zero padding)
-    const float* img = a.x + (size_t)b * a.H * a.W;
-    for (int i = tid; i < CIM * CIM; i += 256) {
-      const int gy = y0 - 2 + i / CIM, gx = x0 - 2 + i % CIM;
-      img_s[i] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? img[(size_t)gy * a.W + gx] : 0.f;
-    }
-    __syncthreads();
-    CONV_FILL_IN(0);
-  } else {
-    CONV_LOAD_IN(0);
+    if (more) CONV_LOAD_IMG(nxin, ny0, nx0);  // 2 registers; stored once this item's last FILL_IN has run
   }
-  CONV_LOAD_W(0);
-  CONV_STORE_IN();
-  CONV_STORE_W(0);
-  __syncthreads();
 
   for (int step = 0; step < nsteps; ++step) {
     const int chunk = step / 9, tap = step - chunk * 9;
     const bool has_next = step + 1 < nsteps;
     const bool new_chunk = has_next && tap == 8;
-    if (has_next) CONV_LOAD_W(step + 1);
-    if (new_chunk) {
-      if constexpr (STEM) { CONV_FILL_IN(chunk + 1); } else { CONV_LOAD_IN(chunk + 1); }
+    // weight slice of the next step (or slice 0 of the next item): requested now, written to the other LDS buffer
+    // after this step's MFMAs.  (Writing it at the top of the following step instead -- "write after the barrier",
+    // +1.4 % on the bare loop shape of tools/micro/mfma_feed.hip -- measured -4 % here: vmcnt retires in order, so
+    // the early write also waits for the older halo-tile loads and the previous item's output stores.)
+    if (has_next) CONV_LOAD_W(wbase, step + 1);
+    else if (more) CONV_LOAD_W(nwbase, 0);
+    if constexpr (STEM) {
+      if (new_chunk) CONV_FILL_IN(chunk + 1, y0, x0);
+      if (more && step == nsteps - 1) CONV_FILL_IN(0, ny0, nx0);
+    } else {
+      // the next input chunk (of this item, or chunk 0 of the next item) is requested LOAD_TAP steps before the
+      // chunk boundary that stores it: first-touch HBM latency is longer than one step under load
+      if (tap == CONV_LOAD_TAP) {
+        if (chunk + 1 < nchunks) { CONV_LOAD_IN(chunk + 1, xin, y0, x0); }
+        else if (more) { CONV_LOAD_IN(0, nxin, ny0, nx0); }
+      }
     }
 
     const int dy = tap / 3, dx = tap - dy * 3;
@@ -279,6 +333,9 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
     if (new_chunk) {
       __syncthreads();  // every wave is done reading the old input chunk
       CONV_STORE_IN();
+    }
+    if constexpr (STEM) {
+      if (more && step == nsteps - 9) CONV_STORE_IMG();  // visible after this step's barrier, read 8 steps later
     }
     __syncthreads();
   }
@@ -346,6 +403,10 @@ __global__ __launch_bounds__(256, KC == 16 ? 3 : 2) void conv3x3_mfma_kernel(Con
       }
     }
   }
+  if (!more) break;
+  item = next_item; x0 = nx0; y0 = ny0; b = nb_b; nb = nnb; xin = nxin; wbase = nwbase;
+  if constexpr (!POOL) __syncthreads();  // the patch reads above are complete before the next halo tile lands in LDS
+  }  // persistent loop over work items
 }
 
 extern "C" int gfc_pack_conv3x3(const float* w_oihw, float* w_packed, int cout, int cin, void* stream) {
@@ -382,23 +443,23 @@ extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* b
     return GFC_OK;
   }
   if (cin % CKC != 0 || cout % CNB != 0) return GFC_ERR_UNSUPPORTED;
-  ConvArgs a;
+  ConvArgs a = {};
   a.x = x; a.w = w_packed; a.bias = bias; a.scale = scale; a.shift = shift; a.y = y;
   a.B = B; a.H = H; a.W = W; a.cin = cin; a.cout = cout; a.relu = relu;
   a.w1 = a.b1 = a.s1 = a.t1 = nullptr;
   return launch_conv(a, pool != 0, false, st);
 }
 
-template <bool POOL, bool STEM, int KC>
+template <bool POOL, bool STEM, int KC, bool PERSIST>
 static int launch_conv_t(const ConvArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)(CH * CH * (KC + 4) + 2 * CNB * (KC + 4) + (STEM ? CIM * CIM : 0)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<POOL, STEM, KC>,
+    (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<POOL, STEM, KC, PERSIST>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv3x3_mfma_kernel<POOL, STEM, KC>), grid, dim3(256), lds, st, a);
+  hipLaunchKernelGGL((conv3x3_mfma_kernel<POOL, STEM, KC, PERSIST>), grid, dim3(256), lds, st, a);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
@@ -406,19 +467,37 @@ static int launch_conv_t(const ConvArgs& a, dim3 grid, hipStream_t st) {
 static int launch_conv(ConvArgs a, bool pool, bool stem, hipStream_t st) {
   a.tiles_x = (a.W + CT - 1) / CT;
   a.tiles_y = (a.H + CT - 1) / CT;
-  dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), a.cout / CNB);
-  // channels per LDS chunk: 16 (36 KB, three workgroups per CU) is 1-2 % faster for the pooled layers (stem: 5.64 ->
-  // 5.55 ms at 32 images), 32 for the un-pooled ones; GFC_CONV_KC=32|16 forces one (tools/bench_kernels.py)
-  static const int forced = [] { const char* e = getenv("GFC_CONV_KC"); return e ? atoi(e) : 0; }();
-  const int kc = forced ? forced : (pool ? 16 : 32);
+  static const int ncu = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  // Variant per layer kind (same-box A/B, tools/ab_build.sh + tools/bench_kernels.py --only conv, 32 VGA images):
+  //  * pooled layers and the stem: 16-channel LDS chunks (36 KB: three workgroups per CU), one workgroup per item
+  //    (persistent workgroups cost the third resident workgroup in registers: stem -1.5 %, conv2b -1 %);
+  //  * un-pooled layers: 32-channel chunks, persistent workgroups (+1.5..2 %; small grids such as conv4a at
+  //    60x80 +16 %, because two resident workgroups per CU then share the items evenly).
+  // GFC_CONV_KC=32|16 and GFC_CONV_PERSIST=0|1 force a variant.
+  static const int forced_kc = [] { const char* e = getenv("GFC_CONV_KC"); return e ? atoi(e) : 0; }();
+  static const int forced_p = [] { const char* e = getenv("GFC_CONV_PERSIST"); return e ? atoi(e) : -1; }();
+  const int kc = forced_kc ? forced_kc : (pool ? 16 : 32);
+  const bool persist = forced_p >= 0 ? forced_p != 0 : !pool;
+  const long long nitems = (long long)a.tiles_x * a.tiles_y * a.B * (a.cout / CNB);
+  const long long resident = (long long)ncu * 2;
+  dim3 grid((unsigned)(persist && nitems > resident ? resident : nitems));
+#define CONV_DISPATCH(KC_, P_)                                                      \
+  do {                                                                              \
+    if (stem) return launch_conv_t<true, true, KC_, P_>(a, grid, st);               \
+    if (pool) return launch_conv_t<true, false, KC_, P_>(a, grid, st);              \
+    return launch_conv_t<false, false, KC_, P_>(a, grid, st);                       \
+  } while (0)
   if (kc == 16) {
-    if (stem) return launch_conv_t<true, true, 16>(a, grid, st);
-    if (pool) return launch_conv_t<true, false, 16>(a, grid, st);
-    return launch_conv_t<false, false, 16>(a, grid, st);
+    if (persist) CONV_DISPATCH(16, true);
+    CONV_DISPATCH(16, false);
   }
-  if (stem) return launch_conv_t<true, true, 32>(a, grid, st);
-  if (pool) return launch_conv_t<true, false, 32>(a, grid, st);
-  return launch_conv_t<false, false, 32>(a, grid, st);
+  if (persist) CONV_DISPATCH(32, true);
+  CONV_DISPATCH(32, false);
+#undef CONV_DISPATCH
 }
 
 // conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in one launch: gray image [B,H,W] -> [B,H/2,W/2,64].
@@ -427,7 +506,7 @@ extern "C" int gfc_sp_stem(const float* image, const float* w1, const float* b1,
                            int H, int W, void* stream) {
   if (!image || !w1 || !b1 || !w2_packed || !b2 || !y || B <= 0 || H < 2 || W < 2) return GFC_ERR_INVALID;
   if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return GFC_ERR_INVALID;
-  ConvArgs a;
+  ConvArgs a = {};
   a.x = image; a.w = w2_packed; a.bias = b2; a.scale = s2; a.shift = t2; a.y = y;
   a.B = B; a.H = H; a.W = W; a.cin = 64; a.cout = 64; a.relu = 1;
   a.w1 = w1; a.b1 = b1; a.s1 = s1; a.t1 = t1;

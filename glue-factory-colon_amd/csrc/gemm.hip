@@ -128,12 +128,19 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
   const int a_off = (wm * WT + l31) * GLD + 4 * h;
   const int b_off = GBM * GLD + (wn * WT + l31) * GLD + 4 * h;
 
+  // Staging order ("write after the barrier"): at the top of K step kt the registers hold tile kt+1 (requested one
+  // whole step earlier); they go to the other LDS buffer first, then tile kt+2 is requested, then the MFMAs of tile kt
+  // run and the step ends on the barrier with no load wait or LDS write in front of it (measured on the loop shape
+  // in tools/micro/mfma_feed.hip: 91.8 -> 93.1 % of the MFMA peak at two workgroups per CU).
   GEMM_LOAD_TILE(0);
   GEMM_STORE_TILE(0);
+  if (ktiles > 1) GEMM_LOAD_TILE(1);
   __syncthreads();
   for (int kt = 0; kt < ktiles; ++kt) {
-    const bool has_next = kt + 1 < ktiles;
-    if (has_next) GEMM_LOAD_TILE(kt + 1);
+    if (kt + 1 < ktiles) {
+      GEMM_STORE_TILE((kt + 1) & 1);
+      if (kt + 2 < ktiles) GEMM_LOAD_TILE(kt + 2);
+    }
     const float* ap = smem + (kt & 1) * TILE + a_off;
     const float* bp = smem + (kt & 1) * TILE + b_off;
 #pragma unroll
@@ -154,7 +161,6 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
           acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
         }
     }
-    if (has_next) GEMM_STORE_TILE((kt + 1) & 1);
     __syncthreads();
   }
 
@@ -303,7 +309,7 @@ extern "C" int gfc_linear(const float* A0, int lda0, int K0, const float* A1, in
   if ((rot_cos == nullptr) != (rot_sin == nullptr)) return GFC_ERR_INVALID;
   if (rot_cos && (rot_cols % 64 != 0)) return GFC_ERR_INVALID;
   if (lda0 % 4 || (A1 && lda1 % 4) || ldw % 4) return GFC_ERR_INVALID;  // 16-byte vector loads
-  GemmArgs g;
+  GemmArgs g = {};
   g.A0 = A0; g.A1 = A1; g.W = W; g.bias = bias; g.scale = scale; g.shift = shift; g.residual = residual;
   g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.Y = Y;
   g.strideA = g.strideW = g.strideY = 0;
@@ -316,7 +322,7 @@ extern "C" int gfc_batched_nt(const float* A, int lda, long long strideA, const 
                               float* Y, int ldy, long long strideY, int M, int N, int K, int batch, void* stream) {
   if (!A || !Bm || !Y || M <= 0 || N <= 0 || K <= 0 || K % GBK || batch <= 0) return GFC_ERR_INVALID;
   if (lda % 4 || ldb % 4 || strideA % 4 || strideB % 4) return GFC_ERR_INVALID;
-  GemmArgs g;
+  GemmArgs g = {};
   g.A0 = A; g.A1 = nullptr; g.W = Bm; g.bias = nullptr; g.scale = nullptr; g.shift = nullptr; g.residual = nullptr;
   g.rot_cos = nullptr; g.rot_sin = nullptr; g.Y = Y;
   g.strideA = strideA; g.strideW = strideB; g.strideY = strideY;
