@@ -145,6 +145,26 @@ def bench_conv():
         report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
 
 
+def bench_stem():
+    """The dominant kernel: conv1a + conv1b + pool in one launch (gfc_sp_stem), 64 VGA images as in bench.py."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    B, h, w = 64, 480, 640
+    img = torch.rand((B, h, w), device=DEV)
+    w1 = torch.randn((9, 64), device=DEV) / 3
+    w2 = torch.randn((9, 64, 64), device=DEV) / 24
+    b1, b2 = torch.randn((64,), device=DEV), torch.randn((64,), device=DEV)
+    s1, s2 = torch.rand((64,), device=DEV) + 0.5, torch.rand((64,), device=DEV) + 0.5
+    t1, t2 = torch.randn((64,), device=DEV), torch.randn((64,), device=DEV)
+    y = torch.empty((B, h // 2, w // 2, 64), device=DEV)
+
+    def fn():
+        nat.check(lib.gfc_sp_stem(nat.ptr(img), nat.ptr(w1), nat.ptr(b1), nat.ptr(s1), nat.ptr(t1), nat.ptr(w2),
+                                  nat.ptr(b2), nat.ptr(s2), nat.ptr(t2), nat.ptr(y), B, h, w, st), "stem")
+
+    report("stem conv1a+conv1b+pool @480x640 x64", timeit(fn, iters=10), 2.0 * 9 * B * h * w * (64 + 64 * 64))
+
+
 def bench_attn():
     lib = nat.lib()
     st = nat.stream_ptr(DEV)
@@ -177,6 +197,8 @@ if __name__ == "__main__":
         bench_gemm_msweep()
     if args.only == "small":
         bench_gemm_small()
+    if args.only in ("", "conv", "stem"):
+        bench_stem()
     if args.only in ("", "conv"):
         bench_conv()
     if args.only in ("", "attn"):
