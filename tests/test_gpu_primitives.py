@@ -2,6 +2,7 @@
 plain torch fp32 on the same seeded inputs.  Integer / index outputs bit-exact; floating point
 within 1e-4 (north-star tolerance), in practice ~1e-6."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -13,6 +14,7 @@ from glue_factory_colon_amd import _native as nat  # noqa: E402
 from oracle import lightglue as olg  # noqa: E402
 from oracle import superpoint as osp  # noqa: E402
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = "cuda"
 _KEEP = []
 
@@ -112,6 +114,59 @@ def test_stem_fused_conv1a_conv1b_pool(h, w, bn):
                               b, h, w, st()), "stem")
     torch.cuda.synchronize()
     assert maxerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize("cin,cout,pool", [(64, 128, False), (64, 64, True), (128, 64, False)])
+def test_conv3x3_many_items_persistent_handover(cin, cout, pool):
+    """More work items than resident workgroups (512-768): persistent workgroups hand over from item to item with the
+    next halo tile / weight slice prefetched; partial border tiles included.  Checked against the one-item-per-
+    workgroup launch of the same kernel family (bit-identical) and against torch."""
+    import subprocess
+    import sys
+
+    lib = nat.lib()
+    g = gen(cin * 3 + cout)
+    b, h, w = 9, 104, 152   # 7 x 10 tiles x 9 images x (cout/64) blocks = 630 / 1260 items
+    x = torch.randn((b, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn((cout,), generator=g) * 0.1
+    scale = torch.rand((cout,), generator=g) + 0.5
+    shift = torch.randn((cout,), generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, wt, bias, padding=1)) * scale[None, :, None, None] + shift[None, :, None, None]
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    wp = torch.empty((9, cout, cin), device=DEV)
+    nat.check(lib.gfc_pack_conv3x3(nat.ptr(D(wt)), nat.ptr(wp), cout, cin, st()), "pack")
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
+    nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(D(bias)), nat.ptr(D(scale)), nat.ptr(D(shift)),
+                              nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()), "conv")
+    torch.cuda.synchronize()
+    assert maxerr(y.permute(0, 3, 1, 2), ref) < 2e-5
+    # the other variants of the family (chunk size x persistence) in child processes (the knobs are read once per
+    # process): all within tolerance of torch; for one chunk size the persistent and the one-item-per-workgroup
+    # launch must be bit-identical (same MFMA order, only the staging differs)
+    torch.save({"x": xd.cpu(), "wp": wp.cpu(), "bias": bias, "scale": scale, "shift": shift, "pool": pool,
+                "ref": ref.permute(0, 2, 3, 1).contiguous()}, "/tmp/gfc_conv_variants.pt")
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from glue_factory_colon_amd import _native as nat\n"
+        "d = torch.load('/tmp/gfc_conv_variants.pt'); dev = torch.device('cuda', 0); lib = nat.lib()\n"
+        "x, wp, bi, sc, sh = (d[k].to(dev) for k in ('x', 'wp', 'bias', 'scale', 'shift'))\n"
+        "y = torch.full(d['ref'].shape, float('nan'), device=dev)\n"
+        "b, h, w, cin = x.shape; cout = wp.shape[1]\n"
+        "nat.check(lib.gfc_conv3x3(nat.ptr(x), nat.ptr(wp), nat.ptr(bi), nat.ptr(sc), nat.ptr(sh), nat.ptr(y), b, h, w,"
+        " cin, cout, 1, int(d['pool']), nat.stream_ptr(dev)), 'conv')\n"
+        "torch.cuda.synchronize(); err = float((y.cpu() - d['ref']).abs().max()); assert err < 2e-5, err\n"
+        "import hashlib; print('VARIANT_OK', hashlib.sha1(y.cpu().numpy().tobytes()).hexdigest())\n") % ROOT
+    digests = {}
+    for kc, persist in ((16, 0), (16, 1), (32, 0), (32, 1)):
+        env = dict(os.environ, GFC_CONV_KC=str(kc), GFC_CONV_PERSIST=str(persist))
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "VARIANT_OK" in r.stdout, (kc, persist, r.stdout[-300:], r.stderr[-600:])
+        digests[(kc, persist)] = r.stdout.split("VARIANT_OK")[1].split()[0]
+    assert digests[(16, 0)] == digests[(16, 1)] and digests[(32, 0)] == digests[(32, 1)], digests
 
 
 def test_conv3x3_rejects_bad_shapes():
