@@ -161,6 +161,22 @@ class SuperPointRunner:
                                         nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "gfc_sp_nms_select")
         return kpts, ksc, counts
 
+    def mask_scores(self, scores, mask, image_wh):
+        """Open-variant order: pixels outside the specular mask can no longer be selected (in place)."""
+        lib = nat.lib()
+        b, h, w = scores.shape
+        nat.check(lib.gfc_sp_mask_scores(nat.ptr(scores), b, h, w, nat.ptr(mask), mask.shape[-2], mask.shape[-1],
+                                         nat.ptr(image_wh), nat.stream_ptr(scores.device)), "gfc_sp_mask_scores")
+        return scores
+
+    def filter_keypoints(self, kpts, ksc, counts, mask, image_wh, offset=0.0):
+        """Official-variant order: compact the selected key points that lie on the mask (in place, counts updated)."""
+        lib = nat.lib()
+        nat.check(lib.gfc_sp_filter_keypoints(nat.ptr(kpts), nat.ptr(ksc), nat.ptr(counts), kpts.shape[0], kpts.shape[1],
+                                              nat.ptr(mask), mask.shape[-2], mask.shape[-1], nat.ptr(image_wh),
+                                              float(offset), nat.stream_ptr(kpts.device)), "gfc_sp_filter_keypoints")
+        return kpts, ksc, counts
+
     def sample(self, desc_raw, kpts, counts, mode):
         lib = nat.lib()
         b, h8, w8, d = desc_raw.shape
@@ -178,9 +194,24 @@ class SuperPointRunner:
         return x
 
 
+def specular_mask_bytes(data, b, device):
+    """`data["specular_mask"]` ([B,1,H,W] / [B,H,W], any dtype, non-zero = keep; extractors/utils.py:16-20) as
+    contiguous bytes [B,Hm,Wm] on the device, and image_size as int32 [B,2] (w, h) or None."""
+    m = data["specular_mask"]
+    m = m.reshape((b,) + tuple(m.shape[-2:])).to(device)
+    m = (m if m.dtype == torch.bool else m != 0).to(torch.uint8).contiguous()
+    wh = None
+    if data.get("image_size") is not None:
+        # `int(w)` truncates towards zero (utils.py:15-16)
+        wh = data["image_size"].to(device=device).reshape(b, 2).to(torch.int32).contiguous()
+    return m, wh
+
+
 def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection_threshold, max_num_keypoints,
-                  force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs):
-    """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379)."""
+                  force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs, specular=None):
+    """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379).
+    specular: None, "before_topk" (superpoint_open.py:177-188) or "after_topk" (superpoint.py:310-328) when
+    `data["specular_mask"]` is to be applied."""
     image = data["image"]
     nat.require_cuda(image, "data['image']")
     if image.dtype != torch.float32:
@@ -193,13 +224,21 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
     if use_image_size_for_borders and "image_size" in data and remove_borders:
         valid_wh = data["image_size"].to(device=image.device).to(torch.int32).contiguous()
     k = max_num_keypoints
-    if k is not None and 0 < k <= 8192 and nms_radius >= 1 and os.environ.get("GFC_SP_FUSED_SELECT", "1") != "0":
+    smask = smask_wh = None
+    if specular is not None:
+        smask, smask_wh = specular_mask_bytes(data, b, image.device)
+    if (specular != "before_topk" and k is not None and 0 < k <= 8192 and nms_radius >= 1
+            and os.environ.get("GFC_SP_FUSED_SELECT", "1") != "0"):
         kpts, ksc, counts = runner.nms_select(heat, nms_radius, remove_borders or 0, valid_wh, detection_threshold, k)
         core_time_ms = (time.perf_counter() - core_start) * 1e3  # like the reference: no device sync
     else:  # unlimited number of key points: dense suppressed map + ordered scan
         suppressed = runner.nms(heat, nms_radius, remove_borders or 0, valid_wh)
         core_time_ms = (time.perf_counter() - core_start) * 1e3
+        if specular == "before_topk":
+            runner.mask_scores(suppressed, smask, smask_wh)
         kpts, ksc, counts = runner.select(suppressed, detection_threshold, k)
+    if specular == "after_topk":
+        runner.filter_keypoints(kpts, ksc, counts, smask, smask_wh, 0.0)
     if force_num_keypoints:
         if k is None:
             raise ValueError("force_num_keypoints needs max_num_keypoints")

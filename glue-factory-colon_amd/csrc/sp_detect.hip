@@ -626,3 +626,85 @@ extern "C" int gfc_l2norm_rows(float* x, long long rows, int width, void* stream
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
+
+// ---- specular-mask filtering of key points (the Endomapper addition of this reference) --------------------------
+// Replaces filter_keypoints_by_specular_mask (reference gluefactory/models/extractors/utils.py:4-42): a key point
+// survives when the pixels floor/ceil(kp - offset) lie inside the mask (cropped to image_size when given) and the
+// mask is set on all of them.  Two call orders exist in the reference:
+//   * superpoint_open.py:177-188 filters the candidates BEFORE the top-k selection  -> gfc_sp_mask_scores on the
+//     suppressed score map (integer candidates: floor == ceil, one mask pixel per candidate), then gfc_sp_select;
+//   * gluefactory_nonfree/superpoint.py:310-328 filters the selected key points AFTER top-k -> gfc_sp_filter_keypoints
+//     (stable in-place compaction, counts updated).
+__global__ __launch_bounds__(256) void mask_scores_kernel(float* __restrict__ scores, const unsigned char* __restrict__ mask,
+                                                          const int* __restrict__ wh, int H, int W, int Hm, int Wm) {
+  const int b = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  int eh = Hm, ew = Wm;
+  if (wh) { ew = min(ew, wh[2 * b]); eh = min(eh, wh[2 * b + 1]); }  // mask[..., :h, :w]
+  const bool keep = y < eh && x < ew && mask[((size_t)b * Hm + y) * Wm + x] != 0;
+  if (!keep) scores[((size_t)b * H + y) * W + x] = -INFINITY;  // below every detection threshold
+}
+
+extern "C" int gfc_sp_mask_scores(float* scores, int B, int H, int W, const uint8_t* mask, int Hm, int Wm,
+                                  const int32_t* image_wh, void* stream) {
+  if (!scores || !mask || B <= 0 || H <= 0 || W <= 0 || Hm <= 0 || Wm <= 0) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(mask_scores_kernel, dim3((W + 255) / 256, H, B), dim3(256), 0, (hipStream_t)stream, scores, mask,
+                     image_wh, H, W, Hm, Wm);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+#define FK_THREADS 1024
+__global__ __launch_bounds__(FK_THREADS) void filter_keypoints_kernel(float* __restrict__ kpts, float* __restrict__ kscores,
+                                                                      int* __restrict__ counts, int cap,
+                                                                      const unsigned char* __restrict__ mask, int Hm, int Wm,
+                                                                      const int* __restrict__ wh, float offset) {
+  __shared__ int wave_tot[FK_THREADS / 64];
+  __shared__ int base_s;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* kp = kpts + (size_t)b * cap * 2;
+  float* ks = kscores + (size_t)b * cap;
+  const unsigned char* m = mask + (size_t)b * Hm * Wm;
+  int eh = Hm, ew = Wm;
+  if (wh) { ew = min(ew, wh[2 * b]); eh = min(eh, wh[2 * b + 1]); }
+  const int n = min(counts[b], cap);
+  if (tid == 0) base_s = 0;
+  __syncthreads();
+  for (int start = 0; start < n; start += FK_THREADS) {
+    const int i = start + tid;
+    float x = 0.f, y = 0.f, s = 0.f;
+    bool keep = false;
+    if (i < n) {
+      x = kp[2 * i]; y = kp[2 * i + 1]; s = ks[i];
+      const float fx = x - offset, fy = y - offset;
+      const int x0 = (int)floorf(fx), x1 = (int)ceilf(fx), y0 = (int)floorf(fy), y1 = (int)ceilf(fy);
+      if (x0 >= 0 && x1 < ew && y0 >= 0 && y1 < eh)
+        keep = m[(size_t)y0 * Wm + x0] && m[(size_t)y0 * Wm + x1] && m[(size_t)y1 * Wm + x0] && m[(size_t)y1 * Wm + x1];
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();  // all loads of this chunk are done, wave totals visible
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (keep) { kp[2 * (off + before)] = x; kp[2 * (off + before) + 1] = y; ks[off + before] = s; }
+    __syncthreads();
+    if (tid == 0) {
+      int t = 0;
+      for (int w = 0; w < FK_THREADS / 64; ++w) t += wave_tot[w];
+      base_s += t;
+    }
+    __syncthreads();
+  }
+  if (tid == 0) counts[b] = base_s;
+}
+
+extern "C" int gfc_sp_filter_keypoints(float* kpts, float* kscores, int32_t* counts, int B, int cap, const uint8_t* mask,
+                                       int Hm, int Wm, const int32_t* image_wh, float keypoint_offset, void* stream) {
+  if (!kpts || !kscores || !counts || !mask || B <= 0 || cap <= 0 || Hm <= 0 || Wm <= 0) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(filter_keypoints_kernel, dim3(B), dim3(FK_THREADS), 0, (hipStream_t)stream, kpts, kscores,
+                     (int*)counts, cap, mask, Hm, Wm, image_wh, keypoint_offset);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

@@ -95,8 +95,7 @@ class SuperPoint(BaseModel):
             raise NotImplementedError("soft-argmax refinement (superpoint.py:100-116) is not built")
         if self.training and conf_get(conf, "randomize_keypoints_training"):
             raise NotImplementedError("training-time multinomial sampling is out of scope (inference path)")
-        if "specular_mask" in data and conf_get(conf, "filter_specular_keypoints"):
-            raise NotImplementedError("specular_mask filtering (Endomapper) is out of scope")
+        specular = "after_topk" if ("specular_mask" in data and conf_get(conf, "filter_specular_keypoints")) else None
         nat.require_cuda(data["image"], "data['image']")
         device = data["image"].device
         if self._packed is None or self._packed.device != device:
@@ -118,7 +117,7 @@ class SuperPoint(BaseModel):
                 detection_threshold=conf_get(conf, "detection_threshold"), max_num_keypoints=k,
                 force_num_keypoints=conf_get(conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_LEGACY if conf_get(conf, "legacy_sampling") else SAMPLE_FIXED,
-                use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"))
+                use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"), specular=specular)
 
     def loss(self, pred, data):
         raise NotImplementedError

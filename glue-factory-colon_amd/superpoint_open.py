@@ -99,8 +99,7 @@ class SuperPoint(BaseModel):
     def _forward(self, data):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
-        if "specular_mask" in data and conf_get(self.conf, "filter_specular_keypoints"):
-            raise NotImplementedError("specular_mask filtering (Endomapper, extractors/utils.py) is out of scope")
+        specular = "before_topk" if ("specular_mask" in data and conf_get(self.conf, "filter_specular_keypoints")) else None
         nat.require_cuda(data["image"], "data['image']")
         device = data["image"].device
         if self._packed is None or self._packed.device != device:
@@ -114,7 +113,7 @@ class SuperPoint(BaseModel):
                 max_num_keypoints=conf_get(self.conf, "max_num_keypoints"),
                 force_num_keypoints=conf_get(self.conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_OPEN, use_image_size_for_borders=False,
-                dense_outputs=conf_get(self.conf, "dense_outputs"))
+                dense_outputs=conf_get(self.conf, "dense_outputs"), specular=specular)
 
     def loss(self, pred, data):
         raise NotImplementedError

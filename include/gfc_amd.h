@@ -318,6 +318,19 @@ int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_
                                 const float* Hinv, int B, int M, int N, float pos_th, float neg_th, float* out,
                                 int64_t* gt_m0_out, void* stream);
 
+/* Specular-mask filtering of key points (reference gluefactory/models/extractors/utils.py:4-42; mask [B,Hm,Wm] bytes,
+ * non-zero = keep; image_wh nullable [B,2] int32 = (w, h): the mask is cropped to it, key points beyond are dropped).
+ * gfc_sp_mask_scores: the open variant's order (superpoint_open.py:177-188, filter BEFORE top-k): every pixel of the
+ * suppressed score map [B,H,W] outside the mask becomes -inf, then gfc_sp_select runs on it.
+ * gfc_sp_filter_keypoints: the official variant's order (gluefactory_nonfree/superpoint.py:310-328, filter AFTER
+ * top-k): stable in-place compaction of kpts [B,cap,2] (x, y before the +0.5 offset) / kscores [B,cap]; counts [B]
+ * is read and updated.  A key point survives when floor/ceil(kp - keypoint_offset) are inside and the mask is set on
+ * all four pixels (the reference's callers pass keypoint_offset = 0). */
+int gfc_sp_mask_scores(float* scores, int B, int H, int W, const uint8_t* mask, int Hm, int Wm, const int32_t* image_wh,
+                       void* stream);
+int gfc_sp_filter_keypoints(float* kpts, float* kscores, int32_t* counts, int B, int cap, const uint8_t* mask, int Hm,
+                            int Wm, const int32_t* image_wh, float keypoint_offset, void* stream);
+
 /* Weighted DLT homography from the predicted matches and its corner error ("next" row rank 3).  kp0 [B,M,2],
  * kp1 [B,N,2], m0 [B,M] int64 (-1 = unmatched), scores0 [B,M] (the weights), H_gt [B,9] row-major, image_size0 [B,2]
  * = (w, h) of view 0.  H_out [B,9]: normalised-DLT estimate divided by (H[2][2] + 1e-8), all +inf when a pair has

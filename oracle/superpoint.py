@@ -141,6 +141,31 @@ def select_keypoints(scores: Tensor, threshold: float, k: Optional[int]) -> Tupl
     return xy, vals
 
 
+def filter_keypoints_by_specular_mask(keypoints: Tensor, specular_mask: Optional[Tensor], *values, image_size=None,
+                                      keypoint_offset: float = 0.5):
+    """extractors/utils.py:4-42 (the Endomapper addition of this reference): keep the key points whose
+    floor/ceil(kp - offset) pixels are inside the mask (cropped to image_size = (w, h)) and set on all four."""
+    if specular_mask is None or keypoints.numel() == 0:
+        return (keypoints, *values)
+    mask = specular_mask
+    if image_size is not None:
+        w, h = image_size
+        mask = mask[..., : int(h), : int(w)]
+    if mask.ndim == 3:
+        mask = mask.squeeze(0)
+    mask = mask.to(torch.bool)
+    h, w = mask.shape[-2:]
+    xy = keypoints - keypoint_offset
+    x0, x1 = torch.floor(xy[:, 0]).long(), torch.ceil(xy[:, 0]).long()
+    y0, y1 = torch.floor(xy[:, 1]).long(), torch.ceil(xy[:, 1]).long()
+    inside = (x0 >= 0) & (x1 < w) & (y0 >= 0) & (y1 < h)
+    keep = torch.zeros_like(inside)
+    if inside.any():
+        keep[inside] = (mask[y0[inside], x0[inside]] & mask[y0[inside], x1[inside]]
+                        & mask[y1[inside], x0[inside]] & mask[y1[inside], x1[inside]])
+    return (keypoints[keep], *[None if v is None else v[keep] for v in values])
+
+
 # ---------------------------------------------------------------------------- sampling
 def sample_descriptors(keypoints: Tensor, dense: Tensor, s: int = 8, mode: str = "open") -> Tensor:
     """Bilinear read of dense descriptors [B,C,h,w] at integer-pixel keypoints [B,N,2] (x,y),
@@ -170,7 +195,8 @@ def sample_descriptors(keypoints: Tensor, dense: Tensor, s: int = 8, mode: str =
 # ----------------------------------------------------------------------------- forward
 def extract(sd: Dict[str, Tensor], image: Tensor, variant: str = "open", nms_radius: int = 4,
             max_num_keypoints: Optional[int] = None, detection_threshold: float = 0.005, remove_borders: int = 4,
-            legacy_sampling: bool = True, image_size: Optional[Tensor] = None) -> Dict[str, object]:
+            legacy_sampling: bool = True, image_size: Optional[Tensor] = None,
+            specular_mask: Optional[Tensor] = None) -> Dict[str, object]:
     """Full extractor.  Returns per-image lists (ragged) plus the intermediates the parity
     tests compare stage by stage:
       heatmap [B,H,W], nms [B,H,W] (after border kill), keypoints: list of [N_i,2] (x+.5,y+.5),
@@ -191,7 +217,19 @@ def extract(sd: Dict[str, Tensor], image: Tensor, variant: str = "open", nms_rad
         scores: List[Tensor] = []
         descs: List[Tensor] = []
         for i in range(image.shape[0]):
-            xy, sc = select_keypoints(suppressed[i], detection_threshold, max_num_keypoints)
+            isz = None if image_size is None else image_size[i]
+            if specular_mask is not None and variant == "open":
+                # superpoint_open.py:156-190: candidates -> specular filter -> top-k
+                xy, sc = select_keypoints(suppressed[i], detection_threshold, None)
+                xy, sc = filter_keypoints_by_specular_mask(xy, specular_mask[i], sc, image_size=isz, keypoint_offset=0.0)
+                if max_num_keypoints is not None and max_num_keypoints < len(sc):
+                    sc, idx = torch.topk(sc, max_num_keypoints, dim=0, sorted=True)
+                    xy = xy[idx]
+            else:
+                xy, sc = select_keypoints(suppressed[i], detection_threshold, max_num_keypoints)
+                if specular_mask is not None:  # superpoint.py:310-328: top-k -> specular filter
+                    xy, sc = filter_keypoints_by_specular_mask(xy, specular_mask[i], sc, image_size=isz,
+                                                               keypoint_offset=0.0)
             d = sample_descriptors(xy[None], dense[i:i + 1], 8, mode)[0]
             kpts.append(xy + 0.5)
             scores.append(sc)

@@ -137,6 +137,47 @@ def golden_superpoint_open():
     save("superpoint_open", **out)
 
 
+def _specular_masks(b, h, w, seed):
+    """Blobby boolean masks (True = keep), like specular-highlight masks: ~25 % of the pixels dropped."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand((b, 1, h // 8 + 1, w // 8 + 1), generator=g)
+    m = torch.nn.functional.interpolate(low, size=(h, w), mode="bilinear", align_corners=False) > 0.42
+    return m
+
+
+def golden_specular():
+    """The Endomapper addition of this reference: key points filtered by data["specular_mask"]
+    (extractors/utils.py:4-42), before top-k in superpoint_open.py:177-188, after top-k in superpoint.py:310-328."""
+    img = synthetic.synthetic_images(2, 120, 160, seed=21)
+    masks = _specular_masks(2, 120, 160, 5)
+    out = {"image": npy(img), "mask": npy(masks)}
+    m = make_spo(max_num_keypoints=150, detection_threshold=0.0, nms_radius=3)
+    for i in range(2):
+        p = m({"image": img[i:i + 1], "specular_mask": masks[i:i + 1]})
+        out[f"open_k150_kpts_{i}"] = npy(p["keypoints"][0])
+        out[f"open_k150_scores_{i}"] = npy(p["keypoint_scores"][0])
+        out[f"open_k150_desc_{i}"] = npy(p["descriptors"][0])
+    # image_size crops the mask (w, h): key points beyond it are dropped; mask as [B,H,W] floats
+    size = torch.tensor([[131.0, 97.0]])
+    p = m({"image": img[:1], "specular_mask": masks[:1, 0].float(), "image_size": size})
+    out["open_crop_size"] = npy(size)
+    out["open_crop_kpts"] = npy(p["keypoints"][0])
+    out["open_crop_scores"] = npy(p["keypoint_scores"][0])
+    # batched + force_num_keypoints with fewer survivors than k is random padding (not a vector); k small enough here
+    m4 = make_spo(max_num_keypoints=48, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    p = m4({"image": img, "specular_mask": masks})
+    out["open_b2_k48_kpts"] = npy(p["keypoints"])
+    out["open_b2_k48_scores"] = npy(p["keypoint_scores"])
+    # official arithmetic: filter AFTER top-k (fewer than k key points come back)
+    mo = make_sp_official(max_num_keypoints=150, detection_threshold=0.0005, nms_radius=3)
+    for i in range(2):
+        p = mo({"image": img[i:i + 1], "specular_mask": masks[i:i + 1]})
+        out[f"off_k150_kpts_{i}"] = npy(p["keypoints"][0])
+        out[f"off_k150_scores_{i}"] = npy(p["keypoint_scores"][0])
+        out[f"off_k150_desc_{i}"] = npy(p["descriptors"][0])
+    save("specular", **out)
+
+
 # ------------------------------------------------------------------- SuperPoint official
 def golden_superpoint_official():
     img = synthetic.synthetic_images(1, 104, 136, seed=21)
@@ -367,6 +408,10 @@ def golden_homography():
 
 
 if __name__ == "__main__":
+    if "--only-specular" in sys.argv:
+        golden_specular()
+        sys.exit(0)
+    golden_specular()
     golden_homography()
     golden_lightglue_adaptive()
     golden_nn_matcher()

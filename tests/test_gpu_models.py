@@ -65,6 +65,41 @@ def test_superpoint_open_outputs_golden(golden):
                           g["b2_k64_kpts"][i], g["b2_k64_scores"][i], g["b2_k64_desc"][i], radius=3)
 
 
+def test_specular_mask_golden(golden):
+    """data["specular_mask"] (this reference's Endomapper addition): reference golden vectors for both orders."""
+    g = golden("specular")
+    mask = g["mask"].bool()
+    m = spo(max_num_keypoints=150, detection_threshold=0.0, nms_radius=3)
+    for i in range(2):
+        p = m({"image": g["image"][i:i + 1].to(DEV), "specular_mask": mask[i:i + 1].to(DEV)})
+        assert p["keypoints"].shape == (1, 150, 2)
+        compare_keypoints(f"spec_open_{i}", p["keypoints"][0], p["keypoint_scores"][0], p["descriptors"][0],
+                          g[f"open_k150_kpts_{i}"], g[f"open_k150_scores_{i}"], g[f"open_k150_desc_{i}"], radius=3)
+        xy = (p["keypoints"][0].cpu() - 0.5).long()
+        assert mask[i, 0][xy[:, 1], xy[:, 0]].all()
+    # mask given as [B,H,W] floats on the CPU, cropped by image_size
+    p = m({"image": g["image"][:1].to(DEV), "specular_mask": mask[:1, 0].float(), "image_size": g["open_crop_size"].to(DEV)})
+    assert set(map(tuple, p["keypoints"][0].cpu().tolist())) == set(map(tuple, g["open_crop_kpts"].tolist()))
+    # batched, force_num_keypoints
+    p = spo(max_num_keypoints=48, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)(
+        {"image": g["image"].to(DEV), "specular_mask": mask.to(DEV)})
+    for i in range(2):
+        assert set(map(tuple, p["keypoints"][i].cpu().tolist())) == set(map(tuple, g["open_b2_k48_kpts"][i].tolist()))
+    # filter_specular_keypoints: False ignores the mask
+    p0 = spo(max_num_keypoints=150, detection_threshold=0.0, nms_radius=3, filter_specular_keypoints=False)(
+        {"image": g["image"][:1].to(DEV), "specular_mask": mask[:1].to(DEV)})
+    p1 = m({"image": g["image"][:1].to(DEV)})
+    assert torch.equal(p0["keypoints"], p1["keypoints"])
+    # official arithmetic: the filter comes after top-k, fewer than k key points come back
+    mo = superpoint.SuperPoint({"weights": "synthetic", "max_num_keypoints": 150, "detection_threshold": 0.0005,
+                                "nms_radius": 3}).eval().to(DEV)
+    for i in range(2):
+        p = mo({"image": g["image"][i:i + 1].to(DEV), "specular_mask": mask[i:i + 1].to(DEV)})
+        assert p["keypoints"].shape[1] == g[f"off_k150_kpts_{i}"].shape[0] < 150
+        compare_keypoints(f"spec_off_{i}", p["keypoints"][0], p["keypoint_scores"][0], p["descriptors"][0],
+                          g[f"off_k150_kpts_{i}"], g[f"off_k150_scores_{i}"], g[f"off_k150_desc_{i}"], radius=3)
+
+
 def test_superpoint_open_padding_and_errors():
     img = synthetic.synthetic_images(2, 64, 96, seed=3).to(DEV)
     m = spo(max_num_keypoints=512, detection_threshold=0.0, nms_radius=4, force_num_keypoints=True)

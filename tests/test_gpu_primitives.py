@@ -416,6 +416,43 @@ def test_select_ties_and_empty():
     assert (sc[1] == 0).all()
 
 
+def test_specular_filter_kernels_vs_oracle():
+    """gfc_sp_filter_keypoints (stable compaction over several 1024-chunks, fractional key points with the
+    reference's default offset 0.5, image_size crop) and gfc_sp_mask_scores against extractors/utils.py restated."""
+    lib = nat.lib()
+    g = gen(91)
+    b, cap, hm, wm = 3, 2500, 70, 90
+    mask = torch.rand((b, hm, wm), generator=g) > 0.3
+    kp = torch.rand((b, cap, 2), generator=g) * torch.tensor([wm + 4.0, hm + 4.0]) - 2.0  # some outside
+    kp[:, ::3] = kp[:, ::3].round() + 0.5                                              # exact pixel centres too
+    sc = torch.rand((b, cap), generator=g)
+    counts = torch.tensor([cap, 1700, 0], dtype=torch.int32)
+    wh = torch.tensor([[90, 70], [80, 60], [90, 70]], dtype=torch.int32)
+    kd, sd_, cd = kp.clone().to(DEV), sc.clone().to(DEV), counts.clone().to(DEV)
+    nat.check(lib.gfc_sp_filter_keypoints(nat.ptr(kd), nat.ptr(sd_), nat.ptr(cd), b, cap, nat.ptr(D(mask.to(torch.uint8))),
+                                          hm, wm, nat.ptr(D(wh)), 0.5, st()), "filter")
+    torch.cuda.synchronize()
+    for i in range(b):
+        n = int(counts[i])
+        k_ref, s_ref = osp.filter_keypoints_by_specular_mask(kp[i, :n], mask[i], sc[i, :n],
+                                                             image_size=wh[i].float(), keypoint_offset=0.5)
+        assert int(cd[i]) == k_ref.shape[0]
+        assert torch.equal(kd[i, : k_ref.shape[0]].cpu(), k_ref) and torch.equal(sd_[i, : k_ref.shape[0]].cpu(), s_ref)
+    # score-map form: exactly the pixels inside the (cropped) mask keep their score
+    h, w = 64, 88
+    scores = torch.rand((b, h, w), generator=g)
+    sdev = scores.clone().to(DEV)
+    nat.check(lib.gfc_sp_mask_scores(nat.ptr(sdev), b, h, w, nat.ptr(D(mask.to(torch.uint8))), hm, wm, nat.ptr(D(wh)),
+                                     st()), "mask")
+    torch.cuda.synchronize()
+    for i in range(b):
+        keep = torch.zeros((h, w), dtype=torch.bool)
+        eh, ew = min(hm, int(wh[i, 1]), h), min(wm, int(wh[i, 0]), w)
+        keep[:eh, :ew] = mask[i, :eh, :ew]
+        out = sdev[i].cpu()
+        assert torch.equal(out[keep], scores[i][keep]) and torch.isinf(out[~keep]).all() and (out[~keep] < 0).all()
+
+
 @pytest.mark.parametrize("mode,name", [(0, "open"), (1, "legacy"), (2, "fixed")])
 def test_sample_descriptors(mode, name):
     lib = nat.lib()

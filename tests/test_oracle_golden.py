@@ -73,6 +73,37 @@ def test_superpoint_open_outputs(golden):
     close(torch.stack(out["descriptors"]), g["b2_k64_desc"])
 
 
+def test_specular_mask_filter(golden):
+    """The reference's Endomapper addition: open variant filters before top-k, official variant after."""
+    g = golden("specular")
+    sd = weights.superpoint_open_state_dict(0)
+    mask = g["mask"].bool()
+    out = osp.extract(sd, g["image"], "open", nms_radius=3, max_num_keypoints=150, detection_threshold=0.0,
+                      specular_mask=mask)
+    for i in range(2):
+        assert out["keypoints"][i].shape[0] == 150  # filtered first, then top-k: still k key points
+        assert torch.equal(out["keypoints"][i], g[f"open_k150_kpts_{i}"])
+        close(out["keypoint_scores"][i], g[f"open_k150_scores_{i}"], 1e-6)
+        close(out["descriptors"][i], g[f"open_k150_desc_{i}"])
+        xy = (out["keypoints"][i] - 0.5).long()
+        assert mask[i, 0][xy[:, 1], xy[:, 0]].all()
+    out = osp.extract(sd, g["image"][:1], "open", nms_radius=3, max_num_keypoints=150, detection_threshold=0.0,
+                      specular_mask=mask[:1, 0].float(), image_size=g["open_crop_size"])
+    assert torch.equal(out["keypoints"][0], g["open_crop_kpts"])
+    assert out["keypoints"][0][:, 0].max() < 131 and out["keypoints"][0][:, 1].max() < 97
+    out = osp.extract(sd, g["image"], "open", nms_radius=3, max_num_keypoints=48, detection_threshold=0.0,
+                      specular_mask=mask)
+    assert torch.equal(torch.stack(out["keypoints"]), g["open_b2_k48_kpts"])
+    sdo = weights.superpoint_state_dict(0)
+    out = osp.extract(sdo, g["image"], "official", nms_radius=3, max_num_keypoints=150, detection_threshold=0.0005,
+                      specular_mask=mask)
+    for i in range(2):
+        assert out["keypoints"][i].shape[0] < 150  # top-k first, then filtered
+        assert torch.equal(out["keypoints"][i], g[f"off_k150_kpts_{i}"])
+        close(out["keypoint_scores"][i], g[f"off_k150_scores_{i}"], 1e-6)
+        close(out["descriptors"][i], g[f"off_k150_desc_{i}"])
+
+
 def test_superpoint_official(golden):
     g = golden("superpoint_official")
     sd = weights.superpoint_state_dict(0)
