@@ -90,6 +90,7 @@ SIGNATURES = {
     "gfc_nn_match": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int] + [c_void_p] * 7
                      + [c_size_t, c_void_p]),
     "gfc_eval_matches_homography": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 2 + [c_void_p] * 3),
+    "gfc_sp_refine_keypoints": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "gfc_sp_mask_scores": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p] * 2),
     "gfc_sp_filter_keypoints": (c_int, [c_void_p] * 3 + [c_int] * 2 + [c_void_p] + [c_int] * 2 + [c_void_p, c_float, c_void_p]),
     "gfc_eval_homography_dlt": (c_int, [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 3),

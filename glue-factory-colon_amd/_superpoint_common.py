@@ -161,6 +161,13 @@ class SuperPointRunner:
                                         nat.ptr(ws), ws.numel(), nat.stream_ptr(dev)), "gfc_sp_nms_select")
         return kpts, ksc, counts
 
+    def refine_keypoints(self, heat, kpts, counts, radius):
+        lib = nat.lib()
+        b, h, w = heat.shape
+        nat.check(lib.gfc_sp_refine_keypoints(nat.ptr(heat), b, h, w, nat.ptr(kpts), nat.ptr(counts), kpts.shape[1],
+                                              int(radius), nat.stream_ptr(heat.device)), "gfc_sp_refine_keypoints")
+        return kpts
+
     def mask_scores(self, scores, mask, image_wh):
         """Open-variant order: pixels outside the specular mask can no longer be selected (in place)."""
         lib = nat.lib()
@@ -208,7 +215,8 @@ def specular_mask_bytes(data, b, device):
 
 
 def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection_threshold, max_num_keypoints,
-                  force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs, specular=None):
+                  force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs, specular=None,
+                  refinement_radius=0):
     """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379).
     specular: None, "before_topk" (superpoint_open.py:177-188) or "after_topk" (superpoint.py:310-328) when
     `data["specular_mask"]` is to be applied."""
@@ -237,6 +245,8 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
         if specular == "before_topk":
             runner.mask_scores(suppressed, smask, smask_wh)
         kpts, ksc, counts = runner.select(suppressed, detection_threshold, k)
+    if refinement_radius and refinement_radius > 0:  # superpoint.py:302-305: after top-k, before the specular filter
+        runner.refine_keypoints(heat, kpts, counts, refinement_radius)
     if specular == "after_topk":
         runner.filter_keypoints(kpts, ksc, counts, smask, smask_wh, 0.0)
     if force_num_keypoints:

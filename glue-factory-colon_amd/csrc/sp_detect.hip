@@ -708,3 +708,43 @@ extern "C" int gfc_sp_filter_keypoints(float* kpts, float* kscores, int32_t* cou
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
+
+// ---- soft-argmax refinement of the selected key points (official variant only) -----------------------------------
+// Replaces soft_argmax_refinement (reference gluefactory_nonfree/superpoint.py:100-116, applied at :302-305 after the
+// top-k selection): kp += (sum dy*s, sum dx*s) / sum s over the (2r+1)^2 window of the DENSE score map (before NMS),
+// zero outside the map.  The reference builds three dense maps with avg_pool2d / conv2d and gathers at the key points;
+// here each key point evaluates its own window (K << H*W).
+__global__ __launch_bounds__(256) void refine_keypoints_kernel(const float* __restrict__ heat, int H, int W,
+                                                               float* __restrict__ kpts, const int* __restrict__ counts,
+                                                               int cap, int radius) {
+  const int b = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = counts ? min(counts[b], cap) : cap;
+  if (i >= n) return;
+  float* kp = kpts + ((size_t)b * cap + i) * 2;
+  const int x = (int)kp[0], y = (int)kp[1];
+  const float* hm = heat + (size_t)b * H * W;
+  float sum = 0.f, sx = 0.f, sy = 0.f;
+  for (int dy = -radius; dy <= radius; ++dy) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= H) continue;
+    for (int dx = -radius; dx <= radius; ++dx) {
+      const int xx = x + dx;
+      if (xx < 0 || xx >= W) continue;
+      const float s = hm[(size_t)yy * W + xx];
+      sum += s;
+      sx += (float)dx * s;
+      sy += (float)dy * s;
+    }
+  }
+  kp[0] = (float)x + sx / sum;
+  kp[1] = (float)y + sy / sum;
+}
+
+extern "C" int gfc_sp_refine_keypoints(const float* heatmap, int B, int H, int W, float* kpts, const int32_t* counts,
+                                       int cap, int radius, void* stream) {
+  if (!heatmap || !kpts || B <= 0 || H <= 0 || W <= 0 || cap <= 0 || radius < 1) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(refine_keypoints_kernel, dim3((cap + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, heatmap, H,
+                     W, kpts, (const int*)counts, cap, radius);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

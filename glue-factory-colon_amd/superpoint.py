@@ -91,8 +91,6 @@ class SuperPoint(BaseModel):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         conf = self.conf
-        if conf_get(conf, "refinement_radius", 0) and conf_get(conf, "refinement_radius") > 0:
-            raise NotImplementedError("soft-argmax refinement (superpoint.py:100-116) is not built")
         if self.training and conf_get(conf, "randomize_keypoints_training"):
             raise NotImplementedError("training-time multinomial sampling is out of scope (inference path)")
         specular = "after_topk" if ("specular_mask" in data and conf_get(conf, "filter_specular_keypoints")) else None
@@ -117,7 +115,8 @@ class SuperPoint(BaseModel):
                 detection_threshold=conf_get(conf, "detection_threshold"), max_num_keypoints=k,
                 force_num_keypoints=conf_get(conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_LEGACY if conf_get(conf, "legacy_sampling") else SAMPLE_FIXED,
-                use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"), specular=specular)
+                use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"), specular=specular,
+                refinement_radius=conf_get(conf, "refinement_radius", 0) or 0)
 
     def loss(self, pred, data):
         raise NotImplementedError

@@ -25,6 +25,9 @@ class TwoViewPipeline(BaseModel):
         "ground_truth": {"name": None},
         "allow_no_extract": False,
         "run_gt_in_forward": False,
+        # random key-point rotation of one view (two_view_pipeline.py:38-43,161-276): a training augmentation
+        # ("train_only"), never active on the inference path; asking for it at inference time is rejected
+        "keypoint_rotation": {"enabled": False, "max_deg": 180.0, "view": 0, "train_only": True},
     }
     required_data_keys = ["view0", "view1"]
     strict_conf = False
@@ -34,6 +37,9 @@ class TwoViewPipeline(BaseModel):
         for comp in ("filter", "solver", "ground_truth"):
             if conf_get(conf_get(conf, comp, {}), "name"):
                 raise NotImplementedError(f"pipeline component {comp!r} is outside the accelerated hot path")
+        rot = conf_get(conf, "keypoint_rotation", {})
+        if conf_get(rot, "enabled") and not conf_get(rot, "train_only", True):
+            raise NotImplementedError("keypoint_rotation outside training (a random augmentation) is not built")
         ext = conf_get(conf, "extractor")
         if conf_get(ext, "name"):
             self.extractor = get_model(conf_get(ext, "name"))(to_plain(ext))

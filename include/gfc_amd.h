@@ -318,6 +318,13 @@ int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_
                                 const float* Hinv, int B, int M, int N, float pos_th, float neg_th, float* out,
                                 int64_t* gt_m0_out, void* stream);
 
+/* Soft-argmax refinement of selected key points (official variant, `refinement_radius` > 0): kpts [B,cap,2] (x, y,
+ * integer valued, the first counts[b] rows of image b; counts nullable = all cap) move by the score-weighted mean
+ * offset inside the (2*radius+1)^2 window of the dense heat-map [B,H,W] (zero outside).  Replaces
+ * soft_argmax_refinement (gluefactory_nonfree/superpoint.py:100-116, called at :302-305). */
+int gfc_sp_refine_keypoints(const float* heatmap, int B, int H, int W, float* kpts, const int32_t* counts, int cap,
+                            int radius, void* stream);
+
 /* Specular-mask filtering of key points (reference gluefactory/models/extractors/utils.py:4-42; mask [B,Hm,Wm] bytes,
  * non-zero = keep; image_wh nullable [B,2] int32 = (w, h): the mask is cropped to it, key points beyond are dropped).
  * gfc_sp_mask_scores: the open variant's order (superpoint_open.py:177-188, filter BEFORE top-k): every pixel of the

@@ -141,6 +141,21 @@ def select_keypoints(scores: Tensor, threshold: float, k: Optional[int]) -> Tupl
     return xy, vals
 
 
+def soft_argmax_refinement(xy: Tensor, scores: Tensor, radius: int) -> Tensor:
+    """gluefactory_nonfree/superpoint.py:100-116 for one image: xy [N,2] integer-valued (x, y), scores [H,W] the
+    dense heat-map -> xy + score-weighted mean offset in the (2r+1)^2 window (zero padding)."""
+    width = 2 * radius + 1
+    s4 = scores[None, None]
+    sum_ = F.avg_pool2d(s4, width, 1, radius, divisor_override=1)
+    ar = torch.arange(-radius, radius + 1).to(scores)
+    kernel_x = ar[None].expand(width, -1)[None, None]
+    dx = F.conv2d(s4, kernel_x, padding=radius)
+    dy = F.conv2d(s4, kernel_x.transpose(2, 3), padding=radius)
+    dxdy = torch.stack([dx[0, 0], dy[0, 0]], -1) / sum_[0, 0, :, :, None]
+    idx = xy.long()
+    return xy.float() + dxdy[idx[:, 1], idx[:, 0]]
+
+
 def filter_keypoints_by_specular_mask(keypoints: Tensor, specular_mask: Optional[Tensor], *values, image_size=None,
                                       keypoint_offset: float = 0.5):
     """extractors/utils.py:4-42 (the Endomapper addition of this reference): keep the key points whose
@@ -196,7 +211,7 @@ def sample_descriptors(keypoints: Tensor, dense: Tensor, s: int = 8, mode: str =
 def extract(sd: Dict[str, Tensor], image: Tensor, variant: str = "open", nms_radius: int = 4,
             max_num_keypoints: Optional[int] = None, detection_threshold: float = 0.005, remove_borders: int = 4,
             legacy_sampling: bool = True, image_size: Optional[Tensor] = None,
-            specular_mask: Optional[Tensor] = None) -> Dict[str, object]:
+            specular_mask: Optional[Tensor] = None, refinement_radius: int = 0) -> Dict[str, object]:
     """Full extractor.  Returns per-image lists (ragged) plus the intermediates the parity
     tests compare stage by stage:
       heatmap [B,H,W], nms [B,H,W] (after border kill), keypoints: list of [N_i,2] (x+.5,y+.5),
@@ -227,6 +242,8 @@ def extract(sd: Dict[str, Tensor], image: Tensor, variant: str = "open", nms_rad
                     xy = xy[idx]
             else:
                 xy, sc = select_keypoints(suppressed[i], detection_threshold, max_num_keypoints)
+                if refinement_radius > 0 and variant != "open":  # superpoint.py:302-305
+                    xy = soft_argmax_refinement(xy, heat[i], refinement_radius)
                 if specular_mask is not None:  # superpoint.py:310-328: top-k -> specular filter
                     xy, sc = filter_keypoints_by_specular_mask(xy, specular_mask[i], sc, image_size=isz,
                                                                keypoint_offset=0.0)

@@ -175,6 +175,15 @@ def golden_specular():
         out[f"off_k150_kpts_{i}"] = npy(p["keypoints"][0])
         out[f"off_k150_scores_{i}"] = npy(p["keypoint_scores"][0])
         out[f"off_k150_desc_{i}"] = npy(p["descriptors"][0])
+    # soft-argmax refinement (superpoint.py:100-116,302-305): fractional key points, then the 4-pixel mask test
+    mr = make_sp_official(max_num_keypoints=150, detection_threshold=0.0005, nms_radius=3, refinement_radius=2)
+    p = mr({"image": img[:1]})
+    out["refine_kpts"] = npy(p["keypoints"][0])
+    out["refine_scores"] = npy(p["keypoint_scores"][0])
+    out["refine_desc"] = npy(p["descriptors"][0])
+    p = mr({"image": img[1:2], "specular_mask": masks[1:2]})
+    out["refine_spec_kpts"] = npy(p["keypoints"][0])
+    out["refine_spec_scores"] = npy(p["keypoint_scores"][0])
     save("specular", **out)
 
 

@@ -100,6 +100,23 @@ def test_specular_mask_golden(golden):
                           g[f"off_k150_kpts_{i}"], g[f"off_k150_scores_{i}"], g[f"off_k150_desc_{i}"], radius=3)
 
 
+def test_soft_argmax_refinement_golden(golden):
+    g = golden("specular")
+    conf = {"weights": "synthetic", "max_num_keypoints": 150, "detection_threshold": 0.0005, "nms_radius": 3,
+            "refinement_radius": 2}
+    mr = superpoint.SuperPoint(conf).eval().to(DEV)
+    p = mr({"image": g["image"][:1].to(DEV)})
+    # same key points (near-tie order swaps aside): match each to its reference row by the rounded position
+    def by_pixel(k):
+        return {(int(x), int(y)): (x, y) for x, y in k.tolist()}
+    ours, ref = by_pixel(p["keypoints"][0].cpu()), by_pixel(g["refine_kpts"])
+    assert set(ours) == set(ref)
+    assert max(max(abs(ours[q][0] - ref[q][0]), abs(ours[q][1] - ref[q][1])) for q in ref) < 1e-4
+    p = mr({"image": g["image"][1:2].to(DEV), "specular_mask": g["mask"][1:2].bool().to(DEV)})
+    ours, ref = by_pixel(p["keypoints"][0].cpu()), by_pixel(g["refine_spec_kpts"])
+    assert set(ours) == set(ref) and p["keypoints"].shape[1] == g["refine_spec_kpts"].shape[0]
+
+
 def test_superpoint_open_padding_and_errors():
     img = synthetic.synthetic_images(2, 64, 96, seed=3).to(DEV)
     m = spo(max_num_keypoints=512, detection_threshold=0.0, nms_radius=4, force_num_keypoints=True)

@@ -104,6 +104,20 @@ def test_specular_mask_filter(golden):
         close(out["descriptors"][i], g[f"off_k150_desc_{i}"])
 
 
+def test_soft_argmax_refinement(golden):
+    g = golden("specular")
+    sdo = weights.superpoint_state_dict(0)
+    out = osp.extract(sdo, g["image"][:1], "official", nms_radius=3, max_num_keypoints=150, detection_threshold=0.0005,
+                      refinement_radius=2)
+    close(out["keypoints"][0], g["refine_kpts"], 1e-5)
+    assert (out["keypoints"][0] - out["keypoints"][0].round()).abs().max() > 0.05  # really fractional
+    close(out["descriptors"][0], g["refine_desc"])
+    out = osp.extract(sdo, g["image"][1:2], "official", nms_radius=3, max_num_keypoints=150, detection_threshold=0.0005,
+                      refinement_radius=2, specular_mask=g["mask"][1:2].bool())
+    assert out["keypoints"][0].shape == g["refine_spec_kpts"].shape
+    close(out["keypoints"][0], g["refine_spec_kpts"], 1e-5)
+
+
 def test_superpoint_official(golden):
     g = golden("superpoint_official")
     sd = weights.superpoint_state_dict(0)
