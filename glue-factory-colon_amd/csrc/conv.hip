@@ -237,7 +237,11 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
   int a_off[2], b_off[2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
-    int py = 4 * wave + 2 * mt + (l31 >> 4), px = l31 & 15;
+    // MFMA tile (wave, mt) = image rows 2*wave + mt and that + 8, 16 pixels each.  Rows EIGHT apart (not adjacent):
+    // ds_read_b128 is serviced in the lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} on 64 banks, and with an
+    // 18-pixel halo pitch two adjacent rows put lanes 12,13 and 26,27 of a group on the same banks (2-way conflict
+    // on every A read: PMC showed 26-39 % of the LDS cycles were conflict cycles); 8 rows = 144 pixels = 0 mod 16.
+    int py = 2 * wave + mt + 8 * (l31 >> 4), px = l31 & 15;
     a_off[mt] = (py * CH + px) * CLD + 4 * h;
   }
 #pragma unroll
@@ -368,7 +372,7 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const int p = er + 4 * i;  // pixel inside the 2x16 block
-        const int gy = y0 + 4 * wave + 2 * mt + (p >> 4), gx = x0 + (p & 15);
+        const int gy = y0 + 2 * wave + mt + 8 * (p >> 4), gx = x0 + (p & 15);
         const float4 v = *reinterpret_cast<const float4*>(patch + p * ELD + ec);
         if (gy < a.H && gx < a.W)
           *reinterpret_cast<float4*>(a.y + (((size_t)b * a.H + gy) * a.W + gx) * a.cout + nb * CNB + ec) = v;
@@ -381,25 +385,24 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
       const float bi = a.bias[co];
       const float sc = a.scale ? a.scale[co] : 1.f;
       const float sh = a.shift ? a.shift[co] : 0.f;
+      // rows 2*wave (mt 0) and 2*wave + 1 (mt 1) are vertical neighbours, register r and r+1 horizontal ones;
+      // registers 8..15 are the same for the rows 8 further down
+      float v0[16], v1[16];
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        float v[16];
+      for (int r = 0; r < 16; ++r) {
+        float t0 = acc[0][nt][r] + bi, t1 = acc[1][nt][r] + bi;
+        if (a.relu) { t0 = fmaxf(t0, 0.f); t1 = fmaxf(t1, 0.f); }
+        v0[r] = t0 * sc + sh;
+        v1[r] = t1 * sc + sh;
+      }
+      const int Ho = a.H >> 1, Wo = a.W >> 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          float t = acc[mt][nt][r] + bi;
-          if (a.relu) t = fmaxf(t, 0.f);
-          v[r] = t * sc + sh;
-        }
-        const int Ho = a.H >> 1, Wo = a.W >> 1;
-        const int oy = (y0 >> 1) + 2 * wave + mt;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int r = 2 * q;  // r, r+1: horizontal neighbours; r+8, r+9: the row below
-          float m = fmaxf(fmaxf(v[r], v[r + 1]), fmaxf(v[r + 8], v[r + 9]));
-          int pxl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;  // even column inside the 16-wide tile
-          int ox = (x0 >> 1) + (pxl >> 1);
-          if (oy < Ho && ox < Wo) a.y[(((size_t)b * Ho + oy) * Wo + ox) * a.cout + co] = m;
-        }
+      for (int q = 0; q < 8; ++q) {
+        const int r = 2 * q;
+        const float m = fmaxf(fmaxf(v0[r], v0[r + 1]), fmaxf(v1[r], v1[r + 1]));
+        const int pxl = (r & 3) + 8 * ((r >> 2) & 1) + 4 * h;  // even column inside the 16-wide tile
+        const int oy = (y0 >> 1) + wave + 4 * (r >> 3), ox = (x0 >> 1) + (pxl >> 1);
+        if (oy < Ho && ox < Wo) a.y[(((size_t)b * Ho + oy) * Wo + ox) * a.cout + co] = m;
       }
     }
   }
