@@ -168,7 +168,11 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
   // VGPRs (a by-reference lambda capture demoted them to a private-memory array). ----
   float4 wreg0, wreg1;
   float4 ireg[NI];
-  const int st_co = tid / C4, st_c4 = (tid % C4) * 4;  // weight rows st_co (, st_co + 32)
+  // weight rows st_co (, st_co + 32).  16-channel chunks: a ds_write_b128 lane group covers two rows; at a pitch of 20
+  // floats adjacent rows overlap by 4 of the 32 banks, rows four apart do not -> permute rows inside blocks of 8
+  const int stq_ = tid / C4;
+  const int st_co = C4 == 4 ? ((stq_ & ~7) | ((stq_ & 1) << 2) | ((stq_ >> 1) & 3)) : stq_;
+  const int st_c4 = (tid % C4) * 4;
   wreg1 = make_float4(0.f, 0.f, 0.f, 0.f);
 #define CONV_LOAD_W(base_, step_)                                                               \
   do {                                                                                      \

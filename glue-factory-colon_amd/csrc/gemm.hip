@@ -67,7 +67,11 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
   const int ktiles = (g.K0 + g.K1) / BK;
 
   const int s_c4 = (tid % C4) * 4;
-  const int s_r0 = tid / C4;
+  // staged row of this thread.  With a 16-deep K tile a ds_write_b128 lane group (8 consecutive lanes) covers two
+  // rows; at a row pitch of 20 floats adjacent rows overlap by 4 of the 32 banks (2-way conflict, PMC: 33 % of the
+  // LDS cycles), rows FOUR apart do not (20*4 = 80 = 16 mod 32): permute the rows inside each block of 8.
+  const int q_ = tid / C4;
+  const int s_r0 = C4 == 4 ? ((q_ & ~7) | ((q_ & 1) << 2) | ((q_ >> 1) & 3)) : q_;
   // staged rows (clamped; out-of-range rows are never stored by the epilogue).  Named registers and
   // wave-uniform pointer selection: arrays / per-branch loads were demoted to private memory by hipcc.
   const int ar0 = min(m0 + s_r0, g.M - 1), ar1 = min(m0 + s_r0 + RPP, g.M - 1);
