@@ -299,7 +299,10 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)
             if args.workload == "c2":
-                out["cpu_baseline"]["same_gpu_torch_eager"] = torch_eager_same_gpu(dev)
+                try:  # context only: never let the comparison leg cost the measurement line
+                    out["cpu_baseline"]["same_gpu_torch_eager"] = torch_eager_same_gpu(dev)
+                except Exception as e:  # noqa: BLE001
+                    out["cpu_baseline"]["same_gpu_torch_eager"] = {"value": None, "error": repr(e)[:200]}
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
