@@ -60,13 +60,15 @@ class TwoViewPipeline(BaseModel):
         """two_view_pipeline.py:78-102: device-synchronised wall clock + peak-memory delta."""
         mem = None
         if device.type == "cuda":
-            torch.cuda.synchronize(device)
+            # the calling thread's stream (= the whole device in the reference's single-stream use); several export
+            # workers time their own pairs without serialising each other (their memory figures then overlap)
+            torch.cuda.current_stream(device).synchronize()
             baseline = torch.cuda.memory_allocated(device)
             torch.cuda.reset_peak_memory_stats(device)
         start = time.perf_counter()
         out = fn()
         if device.type == "cuda":
-            torch.cuda.synchronize(device)
+            torch.cuda.current_stream(device).synchronize()
             mem = max(torch.cuda.max_memory_allocated(device) - baseline, 0) / (1024 ** 2)
         return out, (time.perf_counter() - start) * 1e3, mem
 

@@ -182,6 +182,37 @@ def test_end_to_end_synthetic_homography_eval(tmp_path):
         assert abs(dlt["H_error_dlt"] - eo) <= 0.05 + 0.01 * eo, (dlt, eo)
 
 
+@pytest.mark.gpu
+def test_export_with_concurrent_workers_equals_sequential(tmp_path):
+    """`workers` > 1: several pairs in flight on their own HIP streams / model replicas -- same records, same order."""
+    from glue_factory_colon_amd import synthetic
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+    pipe = TwoViewPipeline({"extractor": {"name": "extractors.superpoint_open", "weights": "synthetic",
+                                          "max_num_keypoints": 256, "detection_threshold": 0.0, "nms_radius": 3},
+                            "matcher": {"name": "matchers.lightglue", "weights": "synthetic",
+                                        "filter_threshold": 0.1}}).eval()
+
+    def loader():
+        for i in range(7):
+            h, w = (160, 240) if i % 2 else (200, 264)  # sizes differ from pair to pair, as in HPatches
+            v0, v1 = synthetic.synthetic_pairs(1, h, w, seed=300 + i)
+            size = torch.tensor([[float(w), float(h)]])
+            yield {"name": [f"seq/{i}.ppm"], "view0": {"image": v0, "image_size": size, "scales": torch.ones(1, 2)},
+                   "view1": {"image": v1, "image_size": size, "scales": torch.ones(1, 2) * 0.5}}
+
+    keys = ["keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1"]
+    a = ep.load_predictions(ep.export_predictions(loader(), pipe, tmp_path / "seq.npz", keys=keys))
+    b = ep.load_predictions(ep.export_predictions(loader(), pipe, tmp_path / "par.npz", keys=keys, workers=3))
+    assert list(a) == list(b) == [f"seq/{i}.ppm" for i in range(7)]
+    for name in a:
+        for k in keys:
+            assert np.array_equal(a[name][k], b[name][k]), (name, k)
+    # an error inside a worker surfaces in the caller
+    with pytest.raises(ValueError, match="Missing key"):
+        ep.export_predictions(loader(), pipe, tmp_path / "bad.npz", keys=["no_such_key"], workers=2)
+
+
 # ---- rank 3: weighted DLT homography + corner error ----------------------------------------------------------
 def _dlt_case(seed, n_pts, noise, outlier_frac=0.0, H=None):
     g = torch.Generator().manual_seed(seed)
