@@ -33,6 +33,110 @@ struct GemmArgs {
   float alpha;
 };
 
+// Epilogue shared by the GEMM kernels: bias / BN affine / alpha directly from the accumulator layout, or -- when
+// rotary or residual operands have to be loaded per element -- through a per-wave LDS transpose with float4 traffic.
+// Called after the K loop's final workgroup barrier (smem is free).
+template <int NW, int MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][MT], float* smem, float* Y, int m0,
+                                              int n0, int wm, int wn, int lane, int wave) {
+  constexpr int WT = 32 * MT;
+  const int l31 = lane & 31, h = lane >> 5;
+  if (g.rot_cos == nullptr && g.residual == nullptr) {
+    // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
+    // measured faster than the LDS transpose below when nothing has to be loaded per element
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt) {
+      const int col = n0 + wn * WT + nt * 32 + l31;
+      const bool col_ok = col < g.N;
+      const int cc = col_ok ? col : g.N - 1;
+      const float bi = g.bias ? g.bias[cc] : 0.f;
+      const float sc = g.scale ? g.scale[cc] : 1.f;
+      const float sh = g.shift ? g.shift[cc] : 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm * WT + mt * 32 + acc_row(r, h);
+          float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
+          if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
+        }
+      }
+    }
+    return;
+  }
+  // Rotary / residual epilogues load per element: in the accumulator layout that is one float per
+  // lane per instruction.  Each wave transposes its tile through its own LDS patch instead (the
+  // K-loop buffers are free now) and handles whole float4 row segments: 4x fewer loads and stores.
+  constexpr int ELD = WT + 4;        // patch row stride (floats): 32 rows x WT cols per round
+  constexpr int LPR = WT / 4;        // lanes per patch row (one float4 each)
+  constexpr int RPS = 64 / LPR;      // rows per step
+  float* patch = smem + wave * 32 * ELD;
+  const bool vec_ok = (g.ldy % 4 == 0) && ((reinterpret_cast<size_t>(Y) & 15) == 0) &&
+                      (!g.residual || (reinterpret_cast<size_t>(g.residual) & 15) == 0);
+  const int er = lane / LPR, ec = (lane % LPR) * 4;  // this lane's row (+RPS per step) and 4 columns
+  const int colb = n0 + wn * WT + ec;
+  float4 bi4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bi4;
+  {
+    float* bp4 = reinterpret_cast<float*>(&bi4);
+    float* sp4 = reinterpret_cast<float*>(&sc4);
+    float* hp4 = reinterpret_cast<float*>(&sh4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cc = min(colb + j, g.N - 1);
+      if (g.bias) bp4[j] = g.bias[cc];
+      if (g.scale) { sp4[j] = g.scale[cc]; hp4[j] = g.shift[cc]; }
+    }
+  }
+  const bool rot = g.rot_cos != nullptr && colb < g.rot_cols;
+  const int rd = colb & 63;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    // The patch is private to the wave and the K loop ended on a workgroup barrier: LDS operations of one wave
+    // complete in order, so only the compiler has to be kept from reordering across the transpose.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int nt = 0; nt < MT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 32 / RPS; ++i) {
+      const int lr = er + RPS * i;
+      const int row = m0 + wm * WT + mt * 32 + lr;
+      float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
+      if (row >= g.M) continue;
+      v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
+      if (rot) {
+        // rotary: out[d] = t[d]*cos[d] + rot(t)[d]*sin[d], rot(t)[2i] = -t[2i+1], rot(t)[2i+1] = t[2i]
+        const float4 c = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row * 64 + rd);
+        const float4 sn = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row * 64 + rd);
+        const float x = v.x, y = v.y, zz = v.z, w = v.w;
+        v.x = x * c.x + (-y) * sn.x;
+        v.y = y * c.y + x * sn.y;
+        v.z = zz * c.z + (-w) * sn.z;
+        v.w = w * c.w + zz * sn.w;
+      }
+      v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+      v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+      const size_t o = (size_t)row * g.ldy + colb;
+      if (vec_ok && colb + 3 < g.N) {
+        if (g.residual) {
+          const float4 rs = *reinterpret_cast<const float4*>(g.residual + o);
+          v.x = rs.x + v.x; v.y = rs.y + v.y; v.z = rs.z + v.z; v.w = rs.w + v.w;
+        }
+        *reinterpret_cast<float4*>(Y + o) = v;
+      } else {
+        const float* vp = reinterpret_cast<const float*>(&v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (colb + j < g.N) Y[o + j] = g.residual ? g.residual[o + j] + vp[j] : vp[j];
+      }
+    }
+  }
+}
+
 // 2 x NW waves; every wave owns MT x MT MFMA tiles of 32x32.
 //   MT = 2, NW = 2, BK = 16: 128x128 tile, 256 threads, 41 KB LDS (3 workgroups / CU)    default for large problems
 //   MT = 2, NW = 4, BK = 32: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup / CU)    knob only
@@ -168,101 +272,122 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
     __syncthreads();
   }
 
-  // ---- epilogue ----
-  if (g.rot_cos == nullptr && g.residual == nullptr) {
-    // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
-    // measured faster than the LDS transpose below when nothing has to be loaded per element
+  gemm_epilogue<NW, MT>(g, acc, smem, Y, m0, n0, wm, wn, lane, wave);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (128x128 tile, 16-deep K tile, 4 waves): operands go global -> LDS with global_load_lds_dwordx4,
+// no staging registers and no ds_write.  One wave-instruction writes 1 KB = 16 unpadded rows of 16 floats, lane i
+// to byte 16*i; bank conflicts of the fragment reads are avoided by an XOR swizzle of the four 16-byte chunks of a
+// row with (row >> 2) & 3, applied to the SOURCE address of the DMA and to the fragment read address (the LDS
+// destination itself has to stay linear).  32 KB of K-loop LDS (34.8 KB with the epilogue patches) and ~100 VGPRs:
+// four workgroups per CU instead of three.
+// ---------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+__global__ __launch_bounds__(256, 4) void gemm_nt_dma_kernel(GemmArgs g) {
+  constexpr int NW = 2, MT = 2, BM = 128, BN = 128, BK = 16;
+  constexpr int TILE = (BM + BN) * BK;  // floats per buffer
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / NW, wn = wave % NW;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const long long z = blockIdx.z;
+  const float* A0 = g.A0 + z * g.strideA;
+  const float* A1 = g.A1 ? g.A1 + z * g.strideA : nullptr;
+  const float* W = g.W + z * g.strideW;
+  float* Y = g.Y + z * g.strideY;
+  const int ktiles = (g.K0 + g.K1) / BK;
+
+  // this lane's share of the wave's four 1 KB pieces (A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of a tile)
+  const int rl = lane >> 2, slot = lane & 3;
+  const int r0 = 32 * wave + rl, r1 = r0 + 16;                 // tile rows of the two pieces
+  const int c0 = 4 * (slot ^ ((r0 >> 2) & 3)), c1 = 4 * (slot ^ ((r1 >> 2) & 3));  // logical k offset of the chunk
+  const size_t ar0 = (size_t)min(m0 + r0, g.M - 1), ar1 = (size_t)min(m0 + r1, g.M - 1);
+  const float* w0p = W + (size_t)min(n0 + r0, g.N - 1) * g.ldw + c0;
+  const float* w1p = W + (size_t)min(n0 + r1, g.N - 1) * g.ldw + c1;
+  // Issued through inline assembly: with the builtin, hipcc drains vmcnt(0) in front of the next ds_read (it cannot
+  // prove that the fragment reads do not alias the DMA destination), which serialises load and compute.  Here the
+  // compiler does not see the outstanding DMA; the wait is placed by hand in front of the barrier that ends the step.
+#define GEMM_GLDS(gsrc_, ldst_)                                                                         \
+  do {                                                                                                  \
+    unsigned keep_;                                                                                     \
+    const unsigned la_ = (unsigned)(size_t)(lds_ptr_t)(ldst_);                                          \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                 : "=&s"(keep_)                                                                         \
+                 : "v"(gsrc_), "s"(__builtin_amdgcn_readfirstlane(la_))                                 \
+                 : "memory");                                                                           \
+  } while (0)
+#define GEMM_DMA_TILE(kt, buf_)                                                                         \
+  do {                                                                                                  \
+    const int k0_ = (kt) * BK;                                                                          \
+    const bool first_ = k0_ < g.K0;                                                                     \
+    const float* ab_ = (first_ ? A0 : A1) + (first_ ? k0_ : k0_ - g.K0);                                \
+    const size_t ld_ = first_ ? g.lda0 : g.lda1;                                                        \
+    float* as_ = smem + (buf_) * TILE + 512 * wave; /* 2 pieces of 256 floats per wave */               \
+    float* bs_ = as_ + BM * BK;                                                                         \
+    GEMM_GLDS(ab_ + ar0 * ld_ + c0, as_);                                                               \
+    GEMM_GLDS(ab_ + ar1 * ld_ + c1, as_ + 256);                                                         \
+    GEMM_GLDS(w0p + k0_, bs_);                                                                          \
+    GEMM_GLDS(w1p + k0_, bs_ + 256);                                                                    \
+  } while (0)
+
+  f32x16 acc[MT][MT];
 #pragma unroll
-    for (int nt = 0; nt < MT; ++nt) {
-      const int col = n0 + wn * WT + nt * 32 + l31;
-      const bool col_ok = col < g.N;
-      const int cc = col_ok ? col : g.N - 1;
-      const float bi = g.bias ? g.bias[cc] : 0.f;
-      const float sc = g.scale ? g.scale[cc] : 1.f;
-      const float sh = g.shift ? g.shift[cc] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WT + mt * 32 + acc_row(r, h);
-          float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
-          if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
-        }
-      }
-    }
-    return;
-  }
-  // Rotary / residual epilogues load per element: in the accumulator layout that is one float per
-  // lane per instruction.  Each wave transposes its tile through its own LDS patch instead (the
-  // K-loop buffers are free now) and handles whole float4 row segments: 4x fewer loads and stores.
-  constexpr int ELD = WT + 4;        // patch row stride (floats): 32 rows x WT cols per round
-  constexpr int LPR = WT / 4;        // lanes per patch row (one float4 each)
-  constexpr int RPS = 64 / LPR;      // rows per step
-  float* patch = smem + wave * 32 * ELD;
-  const bool vec_ok = (g.ldy % 4 == 0) && ((reinterpret_cast<size_t>(Y) & 15) == 0) &&
-                      (!g.residual || (reinterpret_cast<size_t>(g.residual) & 15) == 0);
-  const int er = lane / LPR, ec = (lane % LPR) * 4;  // this lane's row (+RPS per step) and 4 columns
-  const int colb = n0 + wn * WT + ec;
-  float4 bi4 = make_float4(0.f, 0.f, 0.f, 0.f), sc4 = make_float4(1.f, 1.f, 1.f, 1.f), sh4 = bi4;
-  {
-    float* bp4 = reinterpret_cast<float*>(&bi4);
-    float* sp4 = reinterpret_cast<float*>(&sc4);
-    float* hp4 = reinterpret_cast<float*>(&sh4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int cc = min(colb + j, g.N - 1);
-      if (g.bias) bp4[j] = g.bias[cc];
-      if (g.scale) { sp4[j] = g.scale[cc]; hp4[j] = g.shift[cc]; }
-    }
-  }
-  const bool rot = g.rot_cos != nullptr && colb < g.rot_cols;
-  const int rd = colb & 63;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    // The patch is private to the wave and the K loop ended on a workgroup barrier: LDS operations of one wave
-    // complete in order, so only the compiler has to be kept from reordering across the transpose.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
     for (int nt = 0; nt < MT; ++nt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  // fragment rows wm*64 + mt*32 + l31: (row >> 2) & 3 == (l31 >> 2) & 3 for both operands
+  const int sw = (l31 >> 2) & 3;
+  const int a_row = (wm * 64 + l31) * BK, b_row = BM * BK + (wn * 64 + l31) * BK;
+  const int ch0 = 4 * ((0 + h) ^ sw), ch1 = 4 * ((2 + h) ^ sw);  // k group 0: chunk h, k group 1: chunk 2 + h
+
+  GEMM_DMA_TILE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + 1 < ktiles) GEMM_DMA_TILE(kt + 1, (kt + 1) & 1);
+    const float* ap = smem + (kt & 1) * TILE + a_row;
+    const float* bp = smem + (kt & 1) * TILE + b_row;
 #pragma unroll
-    for (int i = 0; i < 32 / RPS; ++i) {
-      const int lr = er + RPS * i;
-      const int row = m0 + wm * WT + mt * 32 + lr;
-      float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
-      if (row >= g.M) continue;
-      v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
-      if (rot) {
-        // rotary: out[d] = t[d]*cos[d] + rot(t)[d]*sin[d], rot(t)[2i] = -t[2i+1], rot(t)[2i+1] = t[2i]
-        const float4 c = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row * 64 + rd);
-        const float4 sn = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row * 64 + rd);
-        const float x = v.x, y = v.y, zz = v.z, w = v.w;
-        v.x = x * c.x + (-y) * sn.x;
-        v.y = y * c.y + x * sn.y;
-        v.z = zz * c.z + (-w) * sn.z;
-        v.w = w * c.w + zz * sn.w;
+    for (int gk = 0; gk < 2; ++gk) {
+      const int ch = gk ? ch1 : ch0;
+      float4 af[MT], bf[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * BK + ch);
+        bf[mt] = *reinterpret_cast<const float4*>(bp + mt * 32 * BK + ch);
       }
-      v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
-      v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
-      const size_t o = (size_t)row * g.ldy + colb;
-      if (vec_ok && colb + 3 < g.N) {
-        if (g.residual) {
-          const float4 rs = *reinterpret_cast<const float4*>(g.residual + o);
-          v.x = rs.x + v.x; v.y = rs.y + v.y; v.z = rs.z + v.z; v.w = rs.w + v.w;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < MT; ++nt) {
+          acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
         }
-        *reinterpret_cast<float4*>(Y + o) = v;
-      } else {
-        const float* vp = reinterpret_cast<const float*>(&v);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (colb + j < g.N) Y[o + j] = g.residual ? g.residual[o + j] + vp[j] : vp[j];
-      }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt+1 has landed
+    __syncthreads();
   }
+#undef GEMM_DMA_TILE
+#undef GEMM_GLDS
+  gemm_epilogue<NW, MT>(g, acc, smem, Y, m0, n0, wm, wn, lane, wave);
+}
+
+static int launch_gemm_dma(const GemmArgs& g, int batch, hipStream_t st) {
+  constexpr size_t kloop = (size_t)2 * 256 * 16, patches = (size_t)2 * 2 * 32 * (64 + 4);
+  const size_t lds = (kloop > patches ? kloop : patches) * sizeof(float);
+  dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
+  hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(256), lds, st, g);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
 }
 
 template <int NW, int MT, int BK>
@@ -299,7 +424,8 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   if (choice == 2) return launch_gemm_t<2, 2, 32>(g, batch, st);
   if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 41 KB LDS: 3 workgroups / CU
   if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
-  if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);  // 128x256, 61 KB LDS: 2 workgroups of 8 waves / CU
+  if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);
+  if (choice == 7) return launch_gemm_dma(g, batch, st);          // 128x128, LDS-DMA staging, 4 workgroups / CU  // 128x256, 61 KB LDS: 2 workgroups of 8 waves / CU
   return launch_gemm_t<2, 1, 32>(g, batch, st);
 }
 

@@ -206,6 +206,20 @@ def test_linear_plain(m, n, k):
     assert maxerr(run_linear(a, w, b, alpha=0.25), F.linear(a, w, b) / 4) < 1e-5
 
 
+def test_gemm_tile_variants_via_knob():
+    """Every GEMM variant behind GFC_GEMM_TILE (128x256, 128x128, 64x64 with 32/16-deep K tiles, the LDS-DMA kernel)
+    passes the linear / batched tests; the knob is read once per process, hence child processes."""
+    import subprocess
+    import sys
+
+    for tile in (1, 2, 3, 5, 6, 7):
+        env = dict(os.environ, GFC_GEMM_TILE=str(tile))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
+                            "-k", "linear_plain or linear_concat or linear_rotary or batched_nt", "-p", "no:cacheprovider"],
+                           capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, (tile, r.stdout[-800:], r.stderr[-400:])
+
+
 def test_linear_concat_residual_affine():
     g = gen(5)
     m = 333
