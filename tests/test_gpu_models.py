@@ -117,6 +117,32 @@ def test_soft_argmax_refinement_golden(golden):
     assert set(ours) == set(ref) and p["keypoints"].shape[1] == g["refine_spec_kpts"].shape[0]
 
 
+def test_run_to_run_determinism_vga_batch():
+    """No atomics-ordered arithmetic, no races in the LDS pipelines / persistent hand-over: the same batch gives
+    bit-identical key points, descriptors, matches and scores run after run (also interleaved with other shapes)."""
+    v0, v1 = synthetic.synthetic_pairs(3, 480, 640, seed=404, device=DEV)
+    size = torch.tensor([[640.0, 480.0]] * 3, device=DEV)
+    ext = spo(max_num_keypoints=1024, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+
+    def run():
+        torch.manual_seed(5)  # pad_random_c draws from torch's generator
+        pj = ext({"image": torch.cat([v0, v1], 0), "image_size": torch.cat([size, size], 0)})
+        p0 = {k: v[:3] for k, v in pj.items()}
+        p1 = {k: v[3:] for k, v in pj.items()}
+        out = mat({"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"], "descriptors0": p0["descriptors"],
+                   "descriptors1": p1["descriptors"], "view0": {"image_size": size}, "view1": {"image_size": size}})
+        return [pj["keypoints"], pj["keypoint_scores"], pj["descriptors"], out["matches0"], out["matching_scores0"],
+                out["log_assignment"]]
+
+    ref = [t.clone() for t in run()]
+    other = synthetic.synthetic_images(1, 200, 264, seed=1).to(DEV)
+    for _ in range(3):
+        ext({"image": other, "image_size": torch.tensor([[264.0, 200.0]], device=DEV)})  # different shape in between
+        for a, b in zip(run(), ref):
+            assert torch.equal(a, b)
+
+
 def test_superpoint_open_padding_and_errors():
     img = synthetic.synthetic_images(2, 64, 96, seed=3).to(DEV)
     m = spo(max_num_keypoints=512, detection_threshold=0.0, nms_radius=4, force_num_keypoints=True)
