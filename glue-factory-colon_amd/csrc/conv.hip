@@ -127,6 +127,7 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
   float* in_s = smem;                   // [CH*CH][CLD]
   float* w_s = smem + CH * CH * CLD;    // [2][CNB][CLD]
   float* img_s = w_s + 2 * CNB * CLD;   // [CIM*CIM] (STEM only)
+  float* c1_s = img_s + CIM * CIM;      // conv1a constants (STEM only): w1 [9][64], b1 [64], s1 [64], t1 [64]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -200,15 +201,14 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
 #define CONV_FILL_IN(chunk_, y0_, x0_)                                                      \
   {                                                                                         \
     const int c0_ = (chunk_) * KC + st_c4;                                                  \
+    /* conv1a constants from LDS (staged once per workgroup): a global load here costs its L2 latency in front  \
+       of every chunk's evaluation (stem +1 %) */                                           \
     float4 wv_[9];                                                                          \
     _Pragma("unroll") for (int t_ = 0; t_ < 9; ++t_)                                        \
-        wv_[t_] = *reinterpret_cast<const float4*>(a.w1 + t_ * 64 + c0_);                   \
-    const float4 b1_ = *reinterpret_cast<const float4*>(a.b1 + c0_);                        \
-    float4 s1_ = make_float4(1.f, 1.f, 1.f, 1.f), t1_ = make_float4(0.f, 0.f, 0.f, 0.f);   \
-    if (a.s1) {                                                                             \
-      s1_ = *reinterpret_cast<const float4*>(a.s1 + c0_);                                   \
-      t1_ = *reinterpret_cast<const float4*>(a.t1 + c0_);                                   \
-    }                                                                                       \
+        wv_[t_] = *reinterpret_cast<const float4*>(c1_s + t_ * 64 + c0_);                   \
+    const float4 b1_ = *reinterpret_cast<const float4*>(c1_s + 576 + c0_);                  \
+    const float4 s1_ = *reinterpret_cast<const float4*>(c1_s + 640 + c0_);                  \
+    const float4 t1_ = *reinterpret_cast<const float4*>(c1_s + 704 + c0_);                  \
     _Pragma("unroll") for (int i_ = 0; i_ < NI; ++i_) {                                     \
       const int idx_ = tid + 256 * i_;                                                      \
       const int p_ = idx_ / C4;                                                             \
@@ -272,6 +272,9 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
   if constexpr (STEM) {
     CONV_LOAD_IMG(xin, y0, x0);
     CONV_STORE_IMG();
+    for (int i = tid; i < 768; i += 256)
+      c1_s[i] = i < 576 ? a.w1[i] : i < 640 ? a.b1[i - 576] : i < 704 ? (a.s1 ? a.s1[i - 640] : 1.f)
+                                                                         : (a.t1 ? a.t1[i - 704] : 0.f);
     __syncthreads();
     CONV_FILL_IN(0, y0, x0);
   } else {
@@ -459,7 +462,7 @@ extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* b
 
 template <bool POOL, bool STEM, int KC, bool PERSIST>
 static int launch_conv_t(const ConvArgs& a, dim3 grid, hipStream_t st) {
-  const size_t lds = (size_t)(CH * CH * (KC + 4) + 2 * CNB * (KC + 4) + (STEM ? CIM * CIM : 0)) * sizeof(float);
+  const size_t lds = (size_t)(CH * CH * (KC + 4) + 2 * CNB * (KC + 4) + (STEM ? CIM * CIM + 768 : 0)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
     (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<POOL, STEM, KC, PERSIST>,
