@@ -40,7 +40,7 @@ _LG_ARRAYS = ["wqkv", "bqkv", "s_out_w", "s_out_b", "s_ffn0_w", "s_ffn0_b", "s_l
 
 class LgParams(Structure):
     _fields_ = ([("n_layers", c_int), ("input_dim", c_int), ("input_proj_w", c_void_p), ("input_proj_b", c_void_p),
-                 ("posenc_wr", c_void_p)]
+                 ("posenc_wr", c_void_p), ("posenc_dim", c_int)]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in _LG_ARRAYS]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in ("final_proj_w", "final_proj_b", "matchability_w",
                                                                "matchability_b", "token_w", "token_b")])
@@ -80,8 +80,8 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     "gfc_l2norm_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p]),
     "gfc_lg_workspace_bytes": (c_size_t, [c_int] * 3),
-    "gfc_lg_posenc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                              c_void_p]),
+    "gfc_lg_posenc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p]),
     "gfc_lg_log_assignment": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t,
                                       c_void_p]),
     "gfc_lg_filter_matches": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -102,7 +102,7 @@ SIGNATURES = {
     "gfc_lg_assign_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_lg_assign": (c_int, [POINTER(LgParams), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                       + [c_void_p] * 6 + [c_size_t, c_void_p]),
-    "gfc_lg_forward": (c_int, [POINTER(LgParams)] + [c_void_p] * 6 + [c_int] * 3 + [c_float] + [c_void_p] * 8
+    "gfc_lg_forward": (c_int, [POINTER(LgParams)] + [c_void_p] * 8 + [c_int] * 3 + [c_float] + [c_void_p] * 8
                        + [c_size_t, c_void_p]),
 }
 

@@ -305,7 +305,8 @@ extern "C" int gfc_lg_assign(const gfc_lg_params* p, int l, const float* x0, con
 }
 
 extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,
-                              const float* desc1, const float* size0, const float* size1, int B, int M, int N,
+                              const float* desc1, const float* size0, const float* size1,
+                              const float* scale_ori0, const float* scale_ori1, int B, int M, int N,
                               float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1,
                               float* log_assignment, float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes,
                               void* stream) {
@@ -314,6 +315,8 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
     return GFC_ERR_INVALID;
   if (B <= 0 || M <= 0 || N <= 0 || p->n_layers <= 0 || p->n_layers > GFC_LG_MAX_LAYERS) return GFC_ERR_INVALID;
   if (p->input_dim != 256 && (!p->input_proj_w || !p->input_proj_b || p->input_dim % 32)) return GFC_ERR_INVALID;
+  const int pdim = p->posenc_dim == 0 ? 2 : p->posenc_dim;
+  if ((pdim != 2 && pdim != 4) || ((pdim == 4) != (scale_ori0 != nullptr && scale_ori1 != nullptr))) return GFC_ERR_INVALID;
   if (ws_bytes < gfc_lg_workspace_bytes(B, M, N)) return GFC_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const LgPlan pl = lg_plan(B, M, N);
@@ -339,7 +342,14 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
   if (hipMemcpyAsync(msg, kpts0, (size_t)R0 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
   if (hipMemcpyAsync(msg + (size_t)R0 * 2, kpts1, (size_t)R1 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return GFC_ERR_LAUNCH;
-  GFC_TRY(gfc_lg_posenc(msg, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, cosb, sinb, st));
+  float* so = nullptr;
+  if (pdim == 4) {  // scale / orientation of both sides packed the same way, behind the key points
+    so = msg + (size_t)R * 2;
+    if (hipMemcpyAsync(so, scale_ori0, (size_t)R0 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
+    if (hipMemcpyAsync(so + (size_t)R0 * 2, scale_ori1, (size_t)R1 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+      return GFC_ERR_LAUNCH;
+  }
+  GFC_TRY(gfc_lg_posenc(msg, so, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, pdim, cosb, sinb, st));
 
   // descriptors -> x (input_proj when input_dim != 256, lightglue.py:352-355,464-465)
   if (p->input_dim == D) {

@@ -6,9 +6,10 @@
 // normalize_keypoints + LearnableFourierPositionalEncoding (lightglue.py:28-40,53-66).
 // cos/sin [rows][64]: value of frequency f stored at 2f and 2f+1 (repeat_interleave(2)).
 // ------------------------------------------------------------------------------------------
-__global__ void posenc_kernel(const float* __restrict__ kpts, const float* __restrict__ sizes,
-                              const int* __restrict__ row0, const int* __restrict__ nrows,
-                              const float* __restrict__ wr, float* __restrict__ cos_out, float* __restrict__ sin_out) {
+__global__ void posenc_kernel(const float* __restrict__ kpts, const float* __restrict__ scale_ori,
+                              const float* __restrict__ sizes, const int* __restrict__ row0,
+                              const int* __restrict__ nrows, const float* __restrict__ wr, int dim,
+                              float* __restrict__ cos_out, float* __restrict__ sin_out) {
   const int img = blockIdx.y;
   const int n = nrows[img];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (row, freq)
@@ -19,18 +20,25 @@ __global__ void posenc_kernel(const float* __restrict__ kpts, const float* __res
   const float half_extent = fmaxf(sw, sh) / 2.f;
   const float kx = (kpts[2 * row] - sw / 2.f) / half_extent;
   const float ky = (kpts[2 * row + 1] - sh / 2.f) / half_extent;
-  float p = kx * wr[2 * f];
-  p += ky * wr[2 * f + 1];
+  float p = kx * wr[dim * f];
+  p += ky * wr[dim * f + 1];
+  if (dim == 4) {  // add_scale_ori: [x, y, scale, orientation] (lightglue.py:436-453), scale / orientation un-normalised
+    p += scale_ori[2 * row] * wr[4 * f + 2];
+    p += scale_ori[2 * row + 1] * wr[4 * f + 3];
+  }
   const float c = cosf(p), s = sinf(p);
   *reinterpret_cast<float2*>(cos_out + row * 64 + 2 * f) = make_float2(c, c);
   *reinterpret_cast<float2*>(sin_out + row * 64 + 2 * f) = make_float2(s, s);
 }
 
-extern "C" int gfc_lg_posenc(const float* kpts, const float* sizes, const int32_t* row0, const int32_t* n,
-                             int n_images, int max_n, const float* wr, float* cos_out, float* sin_out, void* stream) {
+extern "C" int gfc_lg_posenc(const float* kpts, const float* scale_ori, const float* sizes, const int32_t* row0,
+                             const int32_t* n, int n_images, int max_n, const float* wr, int dim, float* cos_out,
+                             float* sin_out, void* stream) {
   if (!kpts || !sizes || !row0 || !n || !wr || !cos_out || !sin_out || n_images <= 0 || max_n <= 0) return GFC_ERR_INVALID;
+  if ((dim != 2 && dim != 4) || ((dim == 4) != (scale_ori != nullptr))) return GFC_ERR_INVALID;
   dim3 grid((max_n * 32 + 255) / 256, n_images);
-  hipLaunchKernelGGL(posenc_kernel, grid, dim3(256), 0, (hipStream_t)stream, kpts, sizes, row0, n, wr, cos_out, sin_out);
+  hipLaunchKernelGGL(posenc_kernel, grid, dim3(256), 0, (hipStream_t)stream, kpts, scale_ori, sizes, row0, n, wr, dim,
+                     cos_out, sin_out);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

@@ -97,8 +97,6 @@ class LightGlue(nn.Module):
         self.conf = conf = Conf(merge(self.default_conf, conf))
         if conf.descriptor_dim != 256 or conf.num_heads != 4:
             raise NotImplementedError("the MI355X kernels are built for descriptor_dim 256, 4 heads (head_dim 64)")
-        if conf.add_scale_ori:
-            raise NotImplementedError("add_scale_ori (SIFT-style scale/orientation inputs) is not built")
         if conf.n_layers > nat.GFC_LG_MAX_LAYERS:
             raise NotImplementedError(f"at most {nat.GFC_LG_MAX_LAYERS} layers")
         if conf.input_dim != conf.descriptor_dim:
@@ -109,7 +107,7 @@ class LightGlue(nn.Module):
             self.input_proj = nn.Identity()
         d, n = conf.descriptor_dim, conf.n_layers
         head_dim = d // conf.num_heads
-        self.posenc = _PosEnc(2, head_dim)
+        self.posenc = _PosEnc(2 + 2 * bool(conf.add_scale_ori), head_dim)  # lightglue.py:358-360
         self.transformers = nn.ModuleList([_Layer(d) for _ in range(n)])
         self.log_assignment = nn.ModuleList([_Assignment(d) for _ in range(n)])
         self.token_confidence = nn.ModuleList([_TokenConfidence(d) for _ in range(n - 1)])
@@ -162,6 +160,7 @@ class LightGlue(nn.Module):
         if conf.input_dim != conf.descriptor_dim:
             p.input_proj_w, p.input_proj_b = dev(self.input_proj.weight), dev(self.input_proj.bias)
         p.posenc_wr = dev(self.posenc.Wr.weight)
+        p.posenc_dim = 4 if self.conf.add_scale_ori else 2
         d, h = conf.descriptor_dim, conf.num_heads
         dh = d // h
         # Wqkv rows: state-dict row = head*(3*dh) + dd*3 + s  ->  packed row = s*d + head*dh + dd
@@ -228,8 +227,15 @@ class LightGlue(nn.Module):
         desc1 = data["descriptors1"].contiguous().float()
         assert desc0.shape[-1] == conf.input_dim
         assert desc1.shape[-1] == conf.input_dim
+        so0 = so1 = None
+        if conf.add_scale_ori:  # lightglue.py:436-453: [x, y, scale, orientation] feeds the positional encoding
+            def pack(sc, ori):
+                sc = sc if sc.dim() == 3 else sc[..., None]
+                ori = ori if ori.dim() == 3 else ori[..., None]
+                return torch.cat([sc, ori], -1).to(device=device, dtype=torch.float32).contiguous()
+            so0, so1 = pack(data["scales0"], data["oris0"]), pack(data["scales1"], data["oris1"])
         if (conf.depth_confidence > 0 or conf.width_confidence > 0) and m > 0 and n > 0:
-            return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1)
+            return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1, so0, so1)
         m0 = torch.full((b, m), -1, device=device, dtype=torch.long)
         m1 = torch.full((b, n), -1, device=device, dtype=torch.long)
         ms0 = torch.zeros((b, m), device=device)
@@ -248,7 +254,7 @@ class LightGlue(nn.Module):
             k1 = kpts1.contiguous().float()
             nat.check(lib.gfc_lg_forward(
                 ctypes.byref(self._packed[0]), nat.ptr(k0), nat.ptr(k1), nat.ptr(desc0), nat.ptr(desc1), nat.ptr(s0),
-                nat.ptr(s1), b, m, n, float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0),
+                nat.ptr(s1), nat.ptr(so0), nat.ptr(so1), b, m, n, float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0),
                 nat.ptr(ms1), nat.ptr(scores), nat.ptr(ref0), nat.ptr(ref1), nat.ptr(ws), ws.numel(),
                 nat.stream_ptr(device)), "gfc_lg_forward")
         # m == 0 or n == 0: the reference's early return (lightglue.py:298-303) -> all -1 / zeros
@@ -265,7 +271,7 @@ class LightGlue(nn.Module):
         }
 
     # -- adaptive depth / width (lightglue.py:500-521,555-580) -----------------------------------
-    def _forward_adaptive(self, kpts0, kpts1, desc0, desc1, size0, size1):
+    def _forward_adaptive(self, kpts0, kpts1, desc0, desc1, size0, size1, so0=None, so1=None):
         """Early stopping (`depth_confidence`) and point pruning (`width_confidence`); batch size 1 like the
         reference (`assert b == 1`, lightglue.py:501,507).  The host drives `gfc_lg_layer` layer by layer, takes
         the stop / prune decisions on the token confidences and matchabilities computed by `gfc_lg_rowdot`
@@ -298,8 +304,10 @@ class LightGlue(nn.Module):
         cnt = torch.tensor([m, n], dtype=torch.int32, device=device)
         cos = torch.empty((m + n, 64), device=device)
         sin = torch.empty((m + n, 64), device=device)
-        nat.check(lib.gfc_lg_posenc(nat.ptr(kp), nat.ptr(sizes), nat.ptr(row0), nat.ptr(cnt), 2, max(m, n),
-                                    params.posenc_wr, nat.ptr(cos), nat.ptr(sin), st), "gfc_lg_posenc")
+        so = torch.cat([so0[0], so1[0]], 0).contiguous() if so0 is not None else None
+        nat.check(lib.gfc_lg_posenc(nat.ptr(kp), nat.ptr(so), nat.ptr(sizes), nat.ptr(row0), nat.ptr(cnt), 2, max(m, n),
+                                    params.posenc_wr, 4 if so is not None else 2, nat.ptr(cos), nat.ptr(sin), st),
+                  "gfc_lg_posenc")
         ind0 = torch.arange(m, device=device)
         ind1 = torch.arange(n, device=device)
         prune0 = torch.ones((1, m), device=device, dtype=torch.long)

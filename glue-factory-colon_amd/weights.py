@@ -124,7 +124,7 @@ def _ffn(sd, prefix, d, seed, out_gain):
 
 
 def lightglue_state_dict(seed: int = 0, input_dim=256, descriptor_dim=256, n_layers=9, num_heads=4,
-                         residual_gain=0.15, qk_gain=2.0, assign_gain=6.0):
+                         residual_gain=0.15, qk_gain=2.0, assign_gain=6.0, add_scale_ori=False):
     """252 tensors (+2 for input_proj when input_dim != descriptor_dim), lightglue.py:349-408.
 
     Gains are chosen so that the random network behaves like a (weak) matcher on a
@@ -138,6 +138,9 @@ def lightglue_state_dict(seed: int = 0, input_dim=256, descriptor_dim=256, n_lay
     if input_dim != d:
         _linear(sd, "input_proj", input_dim, d, seed)
     sd["posenc.Wr.weight"] = _randn("posenc.Wr.weight", seed, (hd // 2, 2), 1.0)
+    if add_scale_ori:  # LearnableFourierPositionalEncoding(2 + 2, ...): columns for scale and orientation
+        sd["posenc.Wr.weight"] = torch.cat([sd["posenc.Wr.weight"],
+                                            _randn("posenc.Wr.weight.so", seed, (hd // 2, 2), 0.3)], 1)
     for i in range(n_layers):
         p = f"transformers.{i}.self_attn"
         _linear(sd, p + ".Wqkv", d, 3 * d, seed, gain=qk_gain)

@@ -206,7 +206,8 @@ typedef struct {
   int input_dim;   /* 256, or 128 with input_proj */
   const float* input_proj_w; /* [256][input_dim] or NULL */
   const float* input_proj_b;
-  const float* posenc_wr;    /* [32][2] */
+  const float* posenc_wr;    /* [32][posenc_dim] */
+  int posenc_dim;            /* 2, or 4 with add_scale_ori (0 is read as 2) */
   /* self block.  wqkv rows re-ordered to [q(256) | k(256) | v(256)], each head-major:
    * new row s*256 + h*64 + d  <-  state-dict row h*192 + d*3 + s   (lightglue.py:157-159) */
   const float* wqkv[GFC_LG_MAX_LAYERS];
@@ -246,10 +247,12 @@ typedef struct {
 size_t gfc_lg_workspace_bytes(int B, int M, int N);
 
 /* Rotary tables: kpts [rows,2] pixel coords, per image i: rows [row0[i], row0[i]+n[i]) are
- * normalised with size[i] = (w,h): (k - size/2) / (max(size)/2), projected by Wr [32][2];
- * cos/sin [rows,64] with each value repeated twice.  lightglue.py:28-40,53-66. */
-int gfc_lg_posenc(const float* kpts, const float* sizes, const int32_t* row0, const int32_t* n, int n_images,
-                  int max_n, const float* wr, float* cos_out, float* sin_out, void* stream);
+ * normalised with size[i] = (w,h): (k - size/2) / (max(size)/2), projected by Wr [32][dim];
+ * cos/sin [rows,64] with each value repeated twice.  lightglue.py:28-40,53-66.
+ * dim = 4 (conf.add_scale_ori, lightglue.py:359,436-453): scale_ori [rows,2] = (scale, orientation) is appended to
+ * the normalised key point before the projection; dim = 2: scale_ori must be NULL. */
+int gfc_lg_posenc(const float* kpts, const float* scale_ori, const float* sizes, const int32_t* row0, const int32_t* n,
+                  int n_images, int max_n, const float* wr, int dim, float* cos_out, float* sin_out, void* stream);
 
 /* log assignment [B,M+1,N+1] from sim [B,M,N] (ld = N), z0 [B,M], z1 [B,N]:
  * sigmoid_log_double_softmax, lightglue.py:257-269.  ws: 2*B*(M+N) floats. */
@@ -286,10 +289,12 @@ int gfc_lg_assign(const gfc_lg_params* p, int layer, const float* x0, const floa
 
 /* Whole matcher: LightGlue.forward (lightglue.py:422-553) with early stop / pruning disabled.
  * kpts0 [B,M,2], kpts1 [B,N,2] (pixel coords), desc0 [B,M,Din], desc1 [B,N,Din],
- * size0/size1 [B,2] = (w,h) floats.  Outputs as filter_matches + log_assignment [B,M+1,N+1]
+ * size0/size1 [B,2] = (w,h) floats; scale_ori0 [B,M,2] / scale_ori1 [B,N,2] = (scales, oris) of the key points when
+ * p->posenc_dim == 4 (add_scale_ori), NULL otherwise.  Outputs as filter_matches + log_assignment [B,M+1,N+1]
  * + ref_desc0 [B,M,256], ref_desc1 [B,N,256] (last-layer descriptors, lightglue.py:495-498). */
 int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,
-                   const float* desc1, const float* size0, const float* size1, int B, int M, int N,
+                   const float* desc1, const float* size0, const float* size1, const float* scale_ori0,
+                   const float* scale_ori1, int B, int M, int N,
                    float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
                    float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes, void* stream);
 

@@ -128,11 +128,15 @@ def filter_matches(scores: Tensor, th: float):
 
 def match(sd: Dict[str, Tensor], kpts0: Tensor, kpts1: Tensor, desc0: Tensor, desc1: Tensor,
           size0: Optional[Tensor], size1: Optional[Tensor], n_layers: int = 9, heads: int = 4,
-          filter_threshold: float = 0.0, return_layers: bool = False) -> Dict[str, Tensor]:
-    """lightglue.py:422-553 with early stopping and pruning disabled."""
+          filter_threshold: float = 0.0, return_layers: bool = False, scale_ori0: Optional[Tensor] = None,
+          scale_ori1: Optional[Tensor] = None) -> Dict[str, Tensor]:
+    """lightglue.py:422-553 with early stopping and pruning disabled.  scale_ori* [B,K,2] = (scales, oris) when the
+    network was built with add_scale_ori (lightglue.py:436-453: appended to the normalised key points)."""
     with torch.no_grad():
         k0 = normalize_keypoints(kpts0, size0)
         k1 = normalize_keypoints(kpts1, size1)
+        if scale_ori0 is not None:
+            k0, k1 = torch.cat([k0, scale_ori0], -1), torch.cat([k1, scale_ori1], -1)
         x0, x1 = desc0.contiguous(), desc1.contiguous()
         if "input_proj.weight" in sd:
             x0, x1 = _linear(sd, "input_proj", x0), _linear(sd, "input_proj", x1)

@@ -416,11 +416,37 @@ def golden_homography():
     save("homography", **out)
 
 
+def golden_scale_ori():
+    """LightGlue with add_scale_ori (SIFT-style inputs: scales0/1, oris0/1 feed the positional encoding)."""
+    sd = weights.lightglue_state_dict(0, add_scale_ori=True)
+    m = ref_lg.LightGlue({"weights": None, "filter_threshold": 0.1, "add_scale_ori": True, "flash": False}).eval()
+    missing = m.load_state_dict(sd, strict=False)
+    assert missing.missing_keys == ["confidence_thresholds"] and not missing.unexpected_keys, missing
+    _, _, p0, p1 = _features(2, 120, 160, 96, 41)
+    kp0, d0 = p0["keypoints"], p0["descriptors"]
+    kp1, d1 = p1["keypoints"][:, :80], p1["descriptors"][:, :80]
+    g = torch.Generator().manual_seed(9)
+    sc0, sc1 = torch.rand((2, 96), generator=g) * 4 + 1, torch.rand((2, 80), generator=g) * 4 + 1
+    or0 = (torch.rand((2, 96, 1), generator=g) - 0.5) * 6.28   # one side [B,K,1], the other [B,K]: both accepted
+    or1 = (torch.rand((2, 80), generator=g) - 0.5) * 6.28
+    size = torch.tensor([[160.0, 120.0]] * 2)
+    out = m({"keypoints0": kp0, "keypoints1": kp1, "descriptors0": d0, "descriptors1": d1, "scales0": sc0, "scales1": sc1,
+             "oris0": or0, "oris1": or1, "view0": {"image_size": size}, "view1": {"image_size": size}})
+    save("scale_ori", keypoints0=npy(kp0), keypoints1=npy(kp1), descriptors0=npy(d0), descriptors1=npy(d1),
+         scales0=npy(sc0), scales1=npy(sc1), oris0=npy(or0), oris1=npy(or1), image_size=npy(size),
+         matches0=npy(out["matches0"]), matches1=npy(out["matches1"]), matching_scores0=npy(out["matching_scores0"]),
+         log_assignment=npy(out["log_assignment"]), ref_descriptors0=npy(out["ref_descriptors0"]))
+
+
 if __name__ == "__main__":
+    if "--only-scale-ori" in sys.argv:
+        golden_scale_ori()
+        sys.exit(0)
     if "--only-specular" in sys.argv:
         golden_specular()
         sys.exit(0)
     golden_specular()
+    golden_scale_ori()
     golden_homography()
     golden_lightglue_adaptive()
     golden_nn_matcher()

@@ -275,6 +275,24 @@ def test_lightglue_layer0_golden(golden):
     assert maxerr(pred["ref_descriptors1"][:, 0], g["layer0_desc1"]) < 5e-5
 
 
+def test_lightglue_add_scale_ori_golden(golden):
+    """SIFT-style inputs: scales / orientations join the key points in the positional encoding (lightglue.py:436-453)."""
+    g = golden("scale_ori")
+    sd = weights.lightglue_state_dict(0, add_scale_ori=True)
+    m = lightglue.LightGlue({"weights": None, "filter_threshold": 0.1, "add_scale_ori": True}).eval()
+    m.load_state_dict(sd, strict=False)
+    m = m.to(DEV)
+    data = {k: g[k].to(DEV) for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1", "scales0", "scales1",
+                                       "oris0", "oris1")}
+    data["view0"] = data["view1"] = {"image_size": g["image_size"].to(DEV)}
+    out = m(data)
+    assert torch.equal(out["matches0"].cpu(), g["matches0"]) and torch.equal(out["matches1"].cpu(), g["matches1"])
+    assert maxerr(out["matching_scores0"], g["matching_scores0"]) < TOL
+    assert maxerr(out["ref_descriptors0"], g["ref_descriptors0"]) < 2e-4
+    with pytest.raises(KeyError):  # the inputs are required once the network is built for them
+        m({k: v for k, v in data.items() if k != "oris1"})
+
+
 def test_lightglue_adaptive_golden_and_early_stop(golden):
     """Adaptive width against the reference's vectors; adaptive depth (early stop) against the oracle
     (the reference's in-tree class cannot return from an early stop in eval mode, see oracle docstring)."""

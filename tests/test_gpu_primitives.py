@@ -542,8 +542,8 @@ def test_posenc(golden):
     sin = torch.empty((b * n, 64), device=DEV)
     row0 = torch.arange(b, dtype=torch.int32, device=DEV) * n
     cnt = torch.full((b,), n, dtype=torch.int32, device=DEV)
-    nat.check(lib.gfc_lg_posenc(nat.ptr(D(kp.reshape(-1, 2).contiguous())), nat.ptr(D(gd["image_size"])),
-                                nat.ptr(row0), nat.ptr(cnt), b, n, nat.ptr(D(wr)), nat.ptr(cos),
+    nat.check(lib.gfc_lg_posenc(nat.ptr(D(kp.reshape(-1, 2).contiguous())), None, nat.ptr(D(gd["image_size"])),
+                                nat.ptr(row0), nat.ptr(cnt), b, n, nat.ptr(D(wr)), 2, nat.ptr(cos),
                                 nat.ptr(sin), st()), "posenc")
     enc = gd["enc0"]  # [2,B,1,N,64]
     assert maxerr(cos.view(b, n, 64), enc[0, :, 0]) < 1e-5

@@ -110,8 +110,9 @@ def test_registry_and_pipeline_contract():
 
 
 def test_lightglue_rejects_out_of_scope_configs():
+    assert lightglue.LightGlue({"add_scale_ori": True}).posenc.Wr.weight.shape == (32, 4)  # built (SIFT-style inputs)
     with pytest.raises(NotImplementedError):
-        lightglue.LightGlue({"add_scale_ori": True})
+        lightglue.LightGlue({"descriptor_dim": 128})
     m = lightglue.LightGlue({"weights": "synthetic", "depth_confidence": 0.95}).eval()
     d = {"keypoints0": torch.zeros(1, 4, 2), "keypoints1": torch.zeros(1, 4, 2), "descriptors0": torch.zeros(1, 4, 256),
          "descriptors1": torch.zeros(1, 4, 256)}

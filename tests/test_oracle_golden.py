@@ -175,6 +175,20 @@ def test_lightglue_ragged_and_128d(golden):
     close(out["log_assignment"], g["d128_log_assignment"], 1e-3)
 
 
+def test_lightglue_add_scale_ori(golden):
+    g = golden("scale_ori")
+    sd = weights.lightglue_state_dict(0, add_scale_ori=True)
+    assert sd["posenc.Wr.weight"].shape == (32, 4)
+    so0 = torch.cat([g["scales0"][..., None], g["oris0"]], -1)            # oris0 came as [B,K,1]
+    so1 = torch.stack([g["scales1"], g["oris1"]], -1)
+    out = olg.match(sd, g["keypoints0"], g["keypoints1"], g["descriptors0"], g["descriptors1"], g["image_size"],
+                    g["image_size"], filter_threshold=0.1, scale_ori0=so0, scale_ori1=so1)
+    assert torch.equal(out["matches0"], g["matches0"]) and torch.equal(out["matches1"], g["matches1"])
+    close(out["matching_scores0"], g["matching_scores0"], 1e-5)
+    close(out["ref_descriptors0"], g["ref_descriptors0"], 1e-4)
+    assert int((g["matches0"] >= 0).sum()) > 40  # a real assignment, not the empty one
+
+
 def test_lightglue_adaptive_pruning(golden):
     """Point pruning (and the depth check on a run that reaches the last layer) against the reference."""
     g = golden("lightglue_adaptive")
