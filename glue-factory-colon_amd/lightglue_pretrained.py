@@ -23,10 +23,11 @@ class LightGlue(BaseModel):
         feats = conf_get(conf, "features")
         if feats not in _FEATURE_DIM:
             raise ValueError(f"unknown features {feats!r}")
-        if feats in ("sift", "doghardnet"):
-            raise NotImplementedError("add_scale_ori feature types are not built")
         self.net = _LightGlue({
             "input_dim": _FEATURE_DIM[feats],
+            # the third-party package's feature table gives sift / doghardnet `add_scale_ori` (scales0/1, oris0/1
+            # forwarded by the wrapper: lightglue_pretrained.py:24-33)
+            "add_scale_ori": feats in ("sift", "doghardnet"),
             "depth_confidence": conf_get(conf, "depth_confidence"),
             "width_confidence": conf_get(conf, "width_confidence"),
             "filter_threshold": conf_get(conf, "filter_threshold"),
