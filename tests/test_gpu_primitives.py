@@ -169,6 +169,48 @@ def test_conv3x3_many_items_persistent_handover(cin, cout, pool):
     assert digests[(16, 0)] == digests[(16, 1)] and digests[(32, 0)] == digests[(32, 1)], digests
 
 
+def test_abi_status_codes_for_bad_arguments():
+    """The C ABI reports misuse through gfc_status, never by faulting: a sweep over the entry points."""
+    lib = nat.lib()
+    x = torch.zeros(4096, device=DEV)
+    xi = torch.zeros(64, device=DEV, dtype=torch.int32)
+    xl = torch.zeros(64, device=DEV, dtype=torch.long)
+    P, s_ = nat.ptr, st()
+    INVALID, WORKSPACE, UNSUPPORTED = 1, 2, 3
+    assert lib.gfc_linear(P(x), 250, 256, None, 0, 0, P(x), 256, None, None, None, 1.0, None, None, None, 0, P(x), 8, 4, 8,
+                          s_) == INVALID                                    # lda not a multiple of 4
+    assert lib.gfc_linear(P(x), 256, 250, None, 0, 0, P(x), 256, None, None, None, 1.0, None, None, None, 0, P(x), 8, 4, 8,
+                          s_) == INVALID                                    # K not a multiple of 32
+    assert lib.gfc_linear(P(x), 256, 256, None, 0, 0, P(x), 256, None, P(x), None, 1.0, None, None, None, 0, P(x), 8, 4, 8,
+                          s_) == INVALID                                    # scale without shift
+    assert lib.gfc_batched_nt(P(x), 64, 0, P(x), 64, 0, P(x), 8, 0, 4, 8, 48, 1, s_) == INVALID
+    assert lib.gfc_attention(P(x), 64, P(x), 64, P(x), 64, P(x), 64, P(xi), 0, 64, 1, 0.125, None, 0, s_) == INVALID
+    assert lib.gfc_layernorm_gelu(None, 512, 4, 512, P(x), P(x), s_) == INVALID
+    assert lib.gfc_sp_nms(P(x), 1, 8, 8, 2, 0, None, None, s_) == INVALID
+    assert lib.gfc_sp_nms(P(x), 1, 8, 8, 7, 0, None, P(x), s_) == UNSUPPORTED  # radius beyond the LDS halo
+    assert lib.gfc_sp_select(P(x), 1, 8, 8, 0.0, 4, 2, P(x), P(x), P(xi), P(x), 1 << 20, s_) == INVALID   # cap < k
+    assert lib.gfc_sp_select(P(x), 1, 8, 8, 0.0, 4, 4, P(x), P(x), P(xi), P(x), 8, s_) == WORKSPACE
+    assert lib.gfc_sp_nms_select(P(x), 1, 16, 16, 0, 0, None, 0.0, 4, 4, None, P(x), P(x), P(xi), P(x), 1 << 20,
+                                 s_) == UNSUPPORTED                         # radius 0: two-stage path
+    assert lib.gfc_sp_nms_select(P(x), 1, 16, 16, 3, 0, None, 0.0, 9000, 9000, None, P(x), P(x), P(xi), P(x), 1 << 20,
+                                 s_) == UNSUPPORTED                         # k > 8192
+    assert lib.gfc_sp_sample(P(x), 1, 2, 2, 256, None, None, 4, 0, P(x), P(x), s_) == INVALID
+    assert lib.gfc_sp_refine_keypoints(P(x), 1, 8, 8, P(x), None, 4, 0, s_) == INVALID         # radius < 1
+    assert lib.gfc_sp_mask_scores(P(x), 1, 8, 8, None, 8, 8, None, s_) == INVALID
+    assert lib.gfc_sp_filter_keypoints(P(x), P(x), P(xi), 1, 0, P(x), 8, 8, None, 0.0, s_) == INVALID
+    assert lib.gfc_lg_posenc(P(x), None, P(x), P(xi), P(xi), 1, 4, P(x), 4, P(x), P(x), s_) == INVALID  # dim 4 w/o scale_ori
+    assert lib.gfc_lg_posenc(P(x), P(x), P(x), P(xi), P(xi), 1, 4, P(x), 2, P(x), P(x), s_) == INVALID  # dim 2 with it
+    assert lib.gfc_lg_posenc(P(x), None, P(x), P(xi), P(xi), 1, 4, P(x), 3, P(x), P(x), s_) == INVALID
+    assert lib.gfc_lg_filter_matches(P(x), 1, 4, 4, 0.1, P(xl), P(xl), P(x), P(x), P(x), 4, s_) == WORKSPACE
+    assert lib.gfc_nn_match(P(x), P(x), 1, 4, 4, 64, 0.0, 0.0, 1, P(xl), P(xl), P(x), P(x), None, None, P(x), 4,
+                            s_) in (INVALID, WORKSPACE)
+    assert lib.gfc_eval_matches_homography(P(x), P(x), P(xl), P(x), None, 1, 4, 4, 3.0, 3.0, P(x), None, s_) == INVALID
+    assert lib.gfc_eval_homography_dlt(P(x), P(x), P(xl), P(x), P(x), P(x), 0, 4, 4, P(x), P(x), s_) == INVALID
+    assert lib.gfc_preprocess_resize(P(x), 0, 0, 1, 1, 8, 8, P(x), 0, 4, 0, 1, s_) == INVALID
+    assert lib.gfc_preprocess_resize(P(x), 0, 0, 1, 1, 4096, 8, P(x), 16, 8, 0, 1, s_) == UNSUPPORTED  # 256x down-scale
+    torch.cuda.synchronize()  # nothing was launched, nothing faulted
+
+
 def test_conv3x3_rejects_bad_shapes():
     lib = nat.lib()
     x = torch.zeros(16, device=DEV)
