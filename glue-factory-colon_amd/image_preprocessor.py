@@ -91,24 +91,23 @@ class ImagePreprocessor:
         return data
 
     def get_new_image_size(self, h: int, w: int):
-        """image.py:105-132."""
-        side = self.conf["side"]
-        rs = self.conf["resize"]
-        if isinstance(rs, collections.Iterable):
-            assert len(rs) == 2
-            return tuple(rs)
-        aspect_ratio = w / h
+        """Target (height, width) for `resize` = edge length on the side named by `side` (image.py:105-132):
+        the named edge gets exactly `resize`, the other one the truncated aspect-preserving length; a 2-element
+        `resize` is taken as (h, w) as it is; `edge_divisible_by` floors both edges to a multiple."""
+        target, side = self.conf["resize"], self.conf["side"]
+        if isinstance(target, collections.Iterable):
+            if len(target) != 2:
+                raise AssertionError("resize must be an int or (h, w)")
+            return tuple(target)
         if side not in ("short", "long", "vert", "horz"):
             raise ValueError(f"side can be one of 'short', 'long', 'vert', and 'horz'. Got '{side}'")
-        if side == "vert":
-            size = rs, int(rs * aspect_ratio)
-        elif side == "horz":
-            size = int(rs / aspect_ratio), rs
-        elif (side == "short") ^ (aspect_ratio < 1.0):
-            size = rs, int(rs * aspect_ratio)
-        else:
-            size = int(rs / aspect_ratio), rs
-        if self.conf["edge_divisible_by"] is not None:
-            df = self.conf["edge_divisible_by"]
-            size = [int(x // df * df) for x in size]
+        ratio = w / h
+        landscape = ratio >= 1.0
+        # which edge is pinned to `target`: the vertical one for "vert", for "short" on landscape images and for
+        # "long" on portrait images
+        pin_height = side == "vert" or (side == "short" and landscape) or (side == "long" and not landscape)
+        size = [target, int(target * ratio)] if pin_height else [int(target / ratio), target]
+        step = self.conf["edge_divisible_by"]
+        if step is not None:
+            size = [int(v // step * step) for v in size]
         return size

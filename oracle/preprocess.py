@@ -57,21 +57,16 @@ def kornia_resize(img: torch.Tensor, size, align_corners=None, antialias=True) -
 
 
 def get_new_image_size(h, w, resize, side="long", edge_divisible_by=None):
-    """image.py:105-132."""
+    """image.py:105-132 restated as a table: (side, orientation) -> which edge is pinned to `resize`."""
     if isinstance(resize, (list, tuple)):
         assert len(resize) == 2
         return tuple(resize)
-    ar = w / h
     if side not in ("short", "long", "vert", "horz"):
         raise ValueError(side)
-    if side == "vert":
-        size = resize, int(resize * ar)
-    elif side == "horz":
-        size = int(resize / ar), resize
-    elif (side == "short") ^ (ar < 1.0):
-        size = resize, int(resize * ar)
-    else:
-        size = int(resize / ar), resize
+    ar = w / h
+    portrait = ar < 1.0
+    pinned = {"vert": "h", "horz": "w", "short": "w" if portrait else "h", "long": "h" if portrait else "w"}[side]
+    size = (resize, int(resize * ar)) if pinned == "h" else (int(resize / ar), resize)
     if edge_divisible_by is not None:
         size = [int(v // edge_divisible_by * edge_divisible_by) for v in size]
     return size
