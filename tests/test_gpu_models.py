@@ -117,6 +117,20 @@ def test_soft_argmax_refinement_golden(golden):
     assert set(ours) == set(ref) and p["keypoints"].shape[1] == g["refine_spec_kpts"].shape[0]
 
 
+@pytest.mark.parametrize("h,w,k", [(16, 24, 32), (24, 40, 64), (8, 8, 16), (40, 1000, 256), (1200, 1600, 2048)])
+def test_superpoint_open_extreme_sizes_vs_oracle(h, w, k):
+    """Tiny maps (a single 8x8 cell: no key point survives the border), a 25:1 strip and a 1200x1600 image:
+    the same key-point set as the oracle, no fault."""
+    img = synthetic.synthetic_images(1, max(h, 8), max(w, 8), seed=h + w)[:, :, :h, :w].contiguous()
+    p = spo(max_num_keypoints=k, detection_threshold=0.0, nms_radius=3)({"image": img.to(DEV)})
+    o = osp.extract(weights.superpoint_open_state_dict(0), img, "open", nms_radius=3, max_num_keypoints=k,
+                    detection_threshold=0.0)
+    ours = set(map(tuple, p["keypoints"][0].cpu().tolist()))
+    ref = set(map(tuple, o["keypoints"][0].tolist()))
+    assert len(ours ^ ref) <= (2 if k >= 1024 else 0), (len(ours), len(ref), len(ours ^ ref))  # top-k boundary ties
+    assert p["descriptors"].shape == (1, len(ours), 256)
+
+
 def test_run_to_run_determinism_vga_batch():
     """No atomics-ordered arithmetic, no races in the LDS pipelines / persistent hand-over: the same batch gives
     bit-identical key points, descriptors, matches and scores run after run (also interleaved with other shapes)."""
