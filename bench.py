@@ -174,6 +174,10 @@ def main():
                          "c4 = configs[3] shape (1024x1024, 2048 kpts) for information")
     ap.add_argument("--joint-extract", type=int, default=1,
                     help="1: run the extractor once on both views' images (2*pairs images per call)")
+    ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split"],
+                    help="3x3 convolutions of the timed path: fp32 MFMA (default) or the experimental bf16x3-split MFMA "
+                         "products at fp32 accuracy; the default run additionally reports the split variant as "
+                         "`experimental_split_conv` (N = 1 only)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU work: exercise only the multi-process plumbing (rendezvous, barriers, max-reduce, "
                          "final gather, JSON) on gloo with a dummy step; never a measurement")
@@ -189,7 +193,8 @@ def main():
     nat.lib()  # fail loudly if the HIP library is missing
 
     ext = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K, "detection_threshold": 0.0,
-                                      "nms_radius": 3, "force_num_keypoints": True}).eval().to(dev)
+                                      "nms_radius": 3, "force_num_keypoints": True,
+                                      "conv_arithmetic": args.conv_arithmetic}).eval().to(dev)
     mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
                                "width_confidence": -1}).eval().to(dev)
     if args.workload == "c4":
@@ -197,7 +202,8 @@ def main():
         STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * H * W
         PAIR_FLOPS = 580.6e9
         ext = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K, "detection_threshold": 0.0,
-                                          "nms_radius": 3, "force_num_keypoints": True}).eval().to(dev)
+                                          "nms_radius": 3, "force_num_keypoints": True,
+                                          "conv_arithmetic": args.conv_arithmetic}).eval().to(dev)
     b = args.pairs
     v0, v1 = synthetic.synthetic_pairs(b, H, W, seed=1234 + rank, device=dev)  # resident in HBM
     size = torch.tensor([[float(W), float(H)]] * b, device=dev)
@@ -205,7 +211,7 @@ def main():
 
     both = {"image": torch.cat([v0, v1], 0), "image_size": torch.cat([size, size], 0)}
 
-    def step():
+    def step(ext=ext):
         if args.joint_extract:
             # both views through ONE extractor call (images are independent: identical results, fewer launches)
             pj = ext(both)
@@ -251,6 +257,31 @@ def main():
 
     durs = trace.durations_ms()
     trace.close()
+
+    # information only: the same steps with the experimental split-bf16 convolutions (opt-in arithmetic, not `value`)
+    split_info = None
+    if world == 1 and args.conv_arithmetic is None and args.workload == "c2":
+        try:
+            ext_s = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K,
+                                                "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True,
+                                                "conv_arithmetic": "split"}).eval().to(dev)
+            with torch.no_grad():
+                for _ in range(args.warmup):
+                    step(ext_s)
+                torch.cuda.synchronize(dev)
+                ts = time.perf_counter()
+                for _ in range(args.steps):
+                    _, _, pred_s = step(ext_s)
+                torch.cuda.synchronize(dev)
+                dts = time.perf_counter() - ts
+            same = (pred_s["matches0"] >= 0).sum().item(), (pred["matches0"] >= 0).sum().item()
+            split_info = {"value": round(b * args.steps / dts, 3), "unit": "image-pairs/sec",
+                          "ms_per_step": round(dts / args.steps * 1e3, 3), "matches_split_vs_fp32": list(same),
+                          "note": "conv_arithmetic='split': 3x3 convolutions as six bf16 MFMA products per fp32 product "
+                                  "(three bf16 planes per operand, fp32 accumulate): fp32-level error, whole parity suite "
+                                  "green (GFC_CONV_MODE=split pytest -m gpu); opt-in, NOT the headline"}
+        except Exception as e:  # noqa: BLE001
+            split_info = {"value": None, "error": repr(e)[:200]}
     if rank == 0:
         allrec = torch.cat(gathered)
         n_pairs_total = allrec.shape[0]
@@ -296,6 +327,11 @@ def main():
                          "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": flops_per_launch},
         }
+        if split_info is not None:
+            out["experimental_split_conv"] = split_info
+        if args.conv_arithmetic == "split":
+            out["dtype"] = "f32 via 3 x bf16 split MFMA in the 3x3 convolutions (experimental), f32 elsewhere"
+            out["roofline"]["note"] = "split arithmetic: the stem is not an fp32-MFMA kernel; frac is fp32-equivalent FLOPs / fp32 peak"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)
             if args.workload == "c2":

@@ -26,7 +26,7 @@ class SpParams(Structure):
                 ("wh", c_void_p), ("bias_h", c_void_p), ("scale_h", c_void_p), ("shift_h", c_void_p),
                 ("wp", c_void_p), ("bias_p", c_void_p), ("scale_p", c_void_p), ("shift_p", c_void_p),
                 ("wd", c_void_p), ("bias_d", c_void_p), ("scale_d", c_void_p), ("shift_d", c_void_p),
-                ("desc_dim", c_int)]
+                ("desc_dim", c_int), ("conv_mode", c_int), ("w_split", c_void_p * 8), ("wh_split", c_void_p)]
 
 
 class Trace(Structure):
@@ -90,6 +90,9 @@ SIGNATURES = {
     "gfc_nn_match": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int] + [c_void_p] * 7
                      + [c_size_t, c_void_p]),
     "gfc_eval_matches_homography": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 2 + [c_void_p] * 3),
+    "gfc_pack_conv3x3_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gfc_conv3x3_split": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_refine_keypoints": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "gfc_sp_mask_scores": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p] * 2),
     "gfc_sp_filter_keypoints": (c_int, [c_void_p] * 3 + [c_int] * 2 + [c_void_p] + [c_int] * 2 + [c_void_p, c_float, c_void_p]),

@@ -25,7 +25,7 @@ def fold_bn(weight, bias, mean, var, eps=1e-3):
 class PackedSuperPoint:
     """Device-resident weights in the layouts of include/gfc_amd.h (gfc_sp_params)."""
 
-    def __init__(self, layers, head_p, head_d, pb, db, device):
+    def __init__(self, layers, head_p, head_d, pb, db, device, conv_mode=None):
         """layers: 8 tuples (w_oihw, bias, scale|None, shift|None) for conv1a..conv4b;
         head_p / head_d: 3x3 128->256 of detector / descriptor (same tuple form);
         pb / db: 1x1 heads (w [C,256,1,1], bias, scale|None, shift|None)."""
@@ -50,14 +50,33 @@ class PackedSuperPoint:
         def opt(t):
             return None if t is None else dev(t)
 
+        # EXPERIMENTAL opt-in: conv_mode "split" (or GFC_CONV_MODE=split) runs the 3x3 convolutions as bf16x3-split
+        # MFMA products at fp32 accuracy (csrc/conv_split.hip); default: fp32 MFMA
+        mode = conv_mode if conv_mode is not None else os.environ.get("GFC_CONV_MODE", "fp32")
+        if mode not in ("fp32", "split"):
+            raise ValueError(f"conv_mode {mode!r}: 'fp32' or 'split'")
+        self.params.conv_mode = 1 if mode == "split" else 0
+
+        def pack_split(w):
+            w = w.detach().to(device=device, dtype=torch.float32).contiguous()
+            out = torch.empty((w.numel() * 3,), device=device, dtype=torch.bfloat16)
+            nat.check(lib.gfc_pack_conv3x3_split(nat.ptr(w), nat.ptr(out), w.shape[0], w.shape[1], st),
+                      "gfc_pack_conv3x3_split")
+            self.keep.append(out)
+            return out
+
         for i, (w, b, sc, sh) in enumerate(layers):
             self.params.w[i] = pack3x3(w).data_ptr()
+            if mode == "split" and i >= 1:
+                self.params.w_split[i] = pack_split(w).data_ptr()
             self.params.bias[i] = dev(b).data_ptr()
             sc, sh = opt(sc), opt(sh)
             self.params.scale[i] = sc.data_ptr() if sc is not None else None
             self.params.shift[i] = sh.data_ptr() if sh is not None else None
         # merged 3x3 heads
         wh = pack3x3(torch.cat([head_p[0], head_d[0]], 0))
+        if mode == "split":
+            self.params.wh_split = pack_split(torch.cat([head_p[0], head_d[0]], 0)).data_ptr()
         bh = dev(torch.cat([head_p[1], head_d[1]], 0))
         self.params.wh, self.params.bias_h = wh.data_ptr(), bh.data_ptr()
         if head_p[2] is not None:

@@ -71,8 +71,11 @@ static int traced_stem(gfc_trace* tr, hipStream_t st, const gfc_sp_params* p, co
                        int W) {
   const bool rec = tr && tr->start && tr->stop && tr->count < tr->capacity;
   if (rec && hipEventRecord((hipEvent_t)tr->start[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
-  int s = gfc_sp_stem(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w[1], p->bias[1], p->scale[1], p->shift[1],
-                      y, B, H, W, st);
+  int s = p->conv_mode == 1
+              ? gfc_sp_stem_split(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_split[1], p->bias[1],
+                                  p->scale[1], p->shift[1], y, B, H, W, st)
+              : gfc_sp_stem(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w[1], p->bias[1], p->scale[1],
+                            p->shift[1], y, B, H, W, st);
   if (s != GFC_OK) return s;
   if (rec) {
     if (hipEventRecord((hipEvent_t)tr->stop[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
@@ -86,6 +89,12 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   if (!p || !image || !heatmap || !desc_raw || !ws || B <= 0 || (C != 1 && C != 3) || H < 8 || W < 8)
     return GFC_ERR_INVALID;
   if (p->desc_dim <= 0) return GFC_ERR_INVALID;
+  if (p->conv_mode != 0 && p->conv_mode != 1) return GFC_ERR_INVALID;
+  if (p->conv_mode == 1) {
+    if (!p->wh_split) return GFC_ERR_INVALID;
+    for (int i = 1; i < 8; ++i)
+      if (!p->w_split[i]) return GFC_ERR_INVALID;
+  }
   if (ws_bytes < gfc_sp_workspace_bytes(B, C, H, W)) return GFC_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   SpPlan pl = sp_plan(B, C, H, W);
@@ -102,17 +111,27 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   const int* Ws = pl.W;
   // conv1a + conv1b + pool in one launch (conv1a is recomputed on the halo tile, never written to HBM)
   GFC_TRY(traced_stem(trace, st, p, x, Bf, B, Hs[1], Ws[1]));
+  // 3x3 layers after the stem: fp32 MFMA (default) or the experimental bf16x3-split arithmetic
+  auto conv = [&](int li, const float* in, float* out, int hh, int ww, int ci, int co, int pool) -> int {
+    if (p->conv_mode == 1)
+      return gfc_conv3x3_split(in, p->w_split[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1,
+                               pool, st);
+    return gfc_conv3x3(in, p->w[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1, pool, st);
+  };
   // conv2a, conv2b+pool
-  GFC_TRY(gfc_conv3x3(Bf, p->w[2], p->bias[2], p->scale[2], p->shift[2], A, B, Hs[2], Ws[2], 64, 64, 1, 0, st));
-  GFC_TRY(gfc_conv3x3(A, p->w[3], p->bias[3], p->scale[3], p->shift[3], Bf, B, Hs[2], Ws[2], 64, 64, 1, 1, st));
+  GFC_TRY(conv(2, Bf, A, Hs[2], Ws[2], 64, 64, 0));
+  GFC_TRY(conv(3, A, Bf, Hs[2], Ws[2], 64, 64, 1));
   // conv3a, conv3b+pool
-  GFC_TRY(gfc_conv3x3(Bf, p->w[4], p->bias[4], p->scale[4], p->shift[4], A, B, Hs[3], Ws[3], 64, 128, 1, 0, st));
-  GFC_TRY(gfc_conv3x3(A, p->w[5], p->bias[5], p->scale[5], p->shift[5], Bf, B, Hs[3], Ws[3], 128, 128, 1, 1, st));
+  GFC_TRY(conv(4, Bf, A, Hs[3], Ws[3], 64, 128, 0));
+  GFC_TRY(conv(5, A, Bf, Hs[3], Ws[3], 128, 128, 1));
   // conv4a, conv4b
-  GFC_TRY(gfc_conv3x3(Bf, p->w[6], p->bias[6], p->scale[6], p->shift[6], A, B, Hs[4], Ws[4], 128, 128, 1, 0, st));
-  GFC_TRY(gfc_conv3x3(A, p->w[7], p->bias[7], p->scale[7], p->shift[7], Bf, B, Hs[4], Ws[4], 128, 128, 1, 0, st));
+  GFC_TRY(conv(6, Bf, A, Hs[4], Ws[4], 128, 128, 0));
+  GFC_TRY(conv(7, A, Bf, Hs[4], Ws[4], 128, 128, 0));
   // merged 3x3 heads: [detector hidden | descriptor hidden]
-  GFC_TRY(gfc_conv3x3(Bf, p->wh, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
+  if (p->conv_mode == 1)
+    GFC_TRY(gfc_conv3x3_split(Bf, p->wh_split, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
+  else
+    GFC_TRY(gfc_conv3x3(Bf, p->wh, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
   const int rows = B * Hs[4] * Ws[4];
   // detector 1x1 -> 65 logits (into Bf), descriptor 1x1 -> desc_raw
   GFC_TRY(gfc_linear(A, 512, 256, nullptr, 0, 0, p->wp, 256, p->bias_p, p->scale_p, p->shift_p, 1.f, nullptr, nullptr,

@@ -85,7 +85,8 @@ class SuperPoint(BaseModel):
             return m.weight, m.bias, None, None
 
         return PackedSuperPoint([cv(getattr(self, n)) for n in _LAYERS], cv(self.convPa), cv(self.convDa),
-                                cv(self.convPb), cv(self.convDb), device)
+                                cv(self.convPb), cv(self.convDb), device,
+                                conv_mode=conf_get(self.conf, "conv_arithmetic", None))
 
     def _forward(self, data):
         if not self.are_weights_initialized:

@@ -43,6 +43,9 @@ class SuperPoint(BaseModel):
         "dense_outputs": None,
         "weights": None,  # local path of pretrained weights; "synthetic[:seed]" = name-seeded weights
         "filter_specular_keypoints": True,
+        # MI355X addition: None = fp32 MFMA (or $GFC_CONV_MODE); "split" = experimental bf16x3-split MFMA products at
+        # fp32 accuracy for the 3x3 convolutions (csrc/conv_split.hip), +24 % end to end
+        "conv_arithmetic": None,
     }
     required_data_keys = ["image"]
 
@@ -94,7 +97,8 @@ class SuperPoint(BaseModel):
 
         layers = [blk(self.backbone[b][j]) for b in range(4) for j in range(2)]
         return PackedSuperPoint(layers, blk(self.detector[0]), blk(self.descriptor[0]), blk(self.detector[1]),
-                                blk(self.descriptor[1]), device)
+                                blk(self.descriptor[1]), device,
+                                conv_mode=conf_get(self.conf, "conv_arithmetic"))
 
     def _forward(self, data):
         if not self.are_weights_initialized:

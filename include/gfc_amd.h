@@ -132,6 +132,12 @@ typedef struct {
   const float* scale_d;
   const float* shift_d;
   int desc_dim;
+  /* EXPERIMENTAL, opt-in: conv_mode = 1 runs the 3x3 convolutions of gfc_sp_dense (conv1b ... conv4b, merged heads)
+   * as bf16x3-split MFMA products at fp32 accuracy (gfc_conv3x3_split); w_split[1..7] / wh_split are the weights
+   * packed by gfc_pack_conv3x3_split (w_split[0] unused: conv1a stays fp32 VALU).  conv_mode = 0 (default): fp32 MFMA. */
+  int conv_mode;
+  const void* w_split[8];
+  const void* wh_split;
 } gfc_sp_params;
 
 typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;
@@ -322,6 +328,19 @@ int gfc_nn_match(const float* desc0, const float* desc1, int B, int M, int N, in
 int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_t* m0, const float* H,
                                 const float* Hinv, int B, int M, int N, float pos_th, float neg_th, float* out,
                                 int64_t* gt_m0_out, void* stream);
+
+/* EXPERIMENTAL, opt-in (not used by gfc_sp_dense): the 3x3 convolution on the bf16 matrix pipe at fp32 accuracy.
+ * Operands are split into three bf16 planes (hi + mid + lo = 24+ mantissa bits) and each fp32 product is evaluated
+ * as six bf16 MFMA products accumulated in fp32 (2.67x the fp32-MFMA peak).  gfc_pack_conv3x3_split: OIHW fp32 ->
+ * [cin/16][9][cout][3][16] bf16 (cout*cin*9*3 bf16 values); gfc_conv3x3_split: same contract as gfc_conv3x3 with
+ * cin % 16 == 0, cout % 64 == 0 (no cin = 1 layer). */
+int gfc_pack_conv3x3_split(const float* w_oihw, void* w_split, int cout, int cin, void* stream);
+int gfc_conv3x3_split(const float* x, const void* w_split, const float* bias, const float* scale, const float* shift,
+                      float* y, int B, int H, int W, int cin, int cout, int relu, int pool, void* stream);
+/* the stem of gfc_sp_stem with conv1b in the split arithmetic (conv1a: fp32 VALU on the halo tile, as there) */
+int gfc_sp_stem_split(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
+                      const void* w2_split, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
+                      int W, void* stream);
 
 /* Soft-argmax refinement of selected key points (official variant, `refinement_radius` > 0): kpts [B,cap,2] (x, y,
  * integer valued, the first counts[b] rows of image b; counts nullable = all cap) move by the score-weighted mean

@@ -211,6 +211,48 @@ def test_abi_status_codes_for_bad_arguments():
     torch.cuda.synchronize()  # nothing was launched, nothing faulted
 
 
+@pytest.mark.parametrize("cin,cout,h,w,pool", [(64, 64, 48, 64, True), (64, 128, 30, 40, False), (128, 128, 33, 47, True),
+                                               (128, 512, 15, 20, False)])
+def test_conv3x3_split_accuracy(cin, cout, h, w, pool):
+    """Experimental bf16x3-split convolution (six bf16 MFMA products per fp32 product): its error against a float64
+    reference must be of the order of the fp32-MFMA kernel's own error (both ~1e-6 here), far inside 1e-4."""
+    lib = nat.lib()
+    g = gen(cin + cout + h + 7)
+    b = 2
+    x = torch.randn((b, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn((cout,), generator=g) * 0.1
+    scale = torch.rand((cout,), generator=g) + 0.5
+    shift = torch.randn((cout,), generator=g) * 0.1
+    ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1)) * scale.double()[None, :, None, None] \
+        + shift.double()[None, :, None, None]
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    outs = {}
+    for name in ("fp32", "split"):
+        y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
+        if name == "fp32":
+            wp = torch.empty((9, cout, cin), device=DEV)
+            nat.check(lib.gfc_pack_conv3x3(nat.ptr(D(wt)), nat.ptr(wp), cout, cin, st()), "pack")
+            nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(D(bias)), nat.ptr(D(scale)), nat.ptr(D(shift)),
+                                      nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()), "conv")
+        else:
+            ws = torch.empty((cout * cin * 9 * 3,), device=DEV, dtype=torch.bfloat16)
+            nat.check(lib.gfc_pack_conv3x3_split(nat.ptr(D(wt)), nat.ptr(ws), cout, cin, st()), "pack_split")
+            nat.check(lib.gfc_conv3x3_split(nat.ptr(xd), nat.ptr(ws), nat.ptr(D(bias)), nat.ptr(D(scale)),
+                                            nat.ptr(D(shift)), nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()),
+                      "conv_split")
+        torch.cuda.synchronize()
+        outs[name] = (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
+    assert outs["split"] < 2e-5 and outs["fp32"] < 2e-5, outs
+    assert outs["split"] < 3 * outs["fp32"] + 1e-6, outs  # same order as the fp32 matrix-pipe kernel
+    from parity_utils import record
+    record(f"conv_split_err_{cin}_{cout}_{h}x{w}_{'pool' if pool else 'nopool'}", split_max_abs_err=outs["split"],
+           fp32_mfma_max_abs_err=outs["fp32"])
+
+
 def test_conv3x3_rejects_bad_shapes():
     lib = nat.lib()
     x = torch.zeros(16, device=DEV)

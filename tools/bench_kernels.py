@@ -145,6 +145,31 @@ def bench_conv():
         report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
 
 
+def bench_conv_split():
+    """Experimental bf16x3-split convolution at the same shapes as bench_conv (TFLOP/s of fp32-equivalent work)."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    B = 32
+    for name, h, w, cin, cout, pool in [("split conv1b 64->64 @480x640 +pool", 480, 640, 64, 64, 1),
+                                        ("split conv2a 64->64 @240x320", 240, 320, 64, 64, 0),
+                                        ("split conv3b 128->128 @120x160 +pool", 120, 160, 128, 128, 1),
+                                        ("split heads 128->512 @60x80", 60, 80, 128, 512, 0)]:
+        x = torch.randn((B, h, w, cin), device=DEV)
+        wt = torch.randn((cout, cin, 3, 3), device=DEV) / (3 * cin ** 0.5)
+        ws = torch.empty((cout * cin * 9 * 3,), device=DEV, dtype=torch.bfloat16)
+        nat.check(lib.gfc_pack_conv3x3_split(nat.ptr(wt), nat.ptr(ws), cout, cin, st), "pack")
+        bias = torch.randn((cout,), device=DEV)
+        sc = torch.rand((cout,), device=DEV) + 0.5
+        sh = torch.randn((cout,), device=DEV)
+        y = torch.empty((B, h // 2 if pool else h, w // 2 if pool else w, cout), device=DEV)
+
+        def fn():
+            nat.check(lib.gfc_conv3x3_split(nat.ptr(x), nat.ptr(ws), nat.ptr(bias), nat.ptr(sc), nat.ptr(sh), nat.ptr(y),
+                                            B, h, w, cin, cout, 1, pool, st), "conv_split")
+
+        report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
+
+
 def bench_stem():
     """The dominant kernel: conv1a + conv1b + pool in one launch (gfc_sp_stem), 64 VGA images as in bench.py."""
     lib = nat.lib()
@@ -197,6 +222,8 @@ if __name__ == "__main__":
         bench_gemm_msweep()
     if args.only == "small":
         bench_gemm_small()
+    if args.only in ("", "split"):
+        bench_conv_split()
     if args.only in ("", "conv", "stem"):
         bench_stem()
     if args.only in ("", "conv"):
