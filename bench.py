@@ -174,6 +174,8 @@ def main():
                          "c4 = configs[3] shape (1024x1024, 2048 kpts) for information")
     ap.add_argument("--joint-extract", type=int, default=1,
                     help="1: run the extractor once on both views' images (2*pairs images per call)")
+    ap.add_argument("--linear-arithmetic", default=None, choices=[None, "fp32", "split"],
+                    help="LightGlue GEMMs of the timed path (see --conv-arithmetic)")
     ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split"],
                     help="3x3 convolutions of the timed path: fp32 MFMA (default) or the experimental bf16x3-split MFMA "
                          "products at fp32 accuracy; the default run additionally reports the split variant as "
@@ -196,7 +198,7 @@ def main():
                                       "nms_radius": 3, "force_num_keypoints": True,
                                       "conv_arithmetic": args.conv_arithmetic}).eval().to(dev)
     mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
-                               "width_confidence": -1}).eval().to(dev)
+                               "width_confidence": -1, "linear_arithmetic": args.linear_arithmetic}).eval().to(dev)
     if args.workload == "c4":
         H, W, K = 1024, 1024, 2048
         STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * H * W
@@ -211,7 +213,7 @@ def main():
 
     both = {"image": torch.cat([v0, v1], 0), "image_size": torch.cat([size, size], 0)}
 
-    def step(ext=ext):
+    def step(ext=ext, mat=mat):
         if args.joint_extract:
             # both views through ONE extractor call (images are independent: identical results, fewer launches)
             pj = ext(both)
@@ -260,26 +262,29 @@ def main():
 
     # information only: the same steps with the experimental split-bf16 convolutions (opt-in arithmetic, not `value`)
     split_info = None
-    if world == 1 and args.conv_arithmetic is None and args.workload == "c2":
+    if world == 1 and args.conv_arithmetic is None and args.linear_arithmetic is None and args.workload == "c2":
         try:
             ext_s = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K,
                                                 "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True,
                                                 "conv_arithmetic": "split"}).eval().to(dev)
+            mat_s = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
+                                         "width_confidence": -1, "linear_arithmetic": "split"}).eval().to(dev)
             with torch.no_grad():
                 for _ in range(args.warmup):
-                    step(ext_s)
+                    step(ext_s, mat_s)
                 torch.cuda.synchronize(dev)
                 ts = time.perf_counter()
                 for _ in range(args.steps):
-                    _, _, pred_s = step(ext_s)
+                    _, _, pred_s = step(ext_s, mat_s)
                 torch.cuda.synchronize(dev)
                 dts = time.perf_counter() - ts
             same = (pred_s["matches0"] >= 0).sum().item(), (pred["matches0"] >= 0).sum().item()
             split_info = {"value": round(b * args.steps / dts, 3), "unit": "image-pairs/sec",
                           "ms_per_step": round(dts / args.steps * 1e3, 3), "matches_split_vs_fp32": list(same),
-                          "note": "conv_arithmetic='split': 3x3 convolutions as six bf16 MFMA products per fp32 product "
-                                  "(three bf16 planes per operand, fp32 accumulate): fp32-level error, whole parity suite "
-                                  "green (GFC_CONV_MODE=split pytest -m gpu); opt-in, NOT the headline"}
+                          "note": "conv_arithmetic='split' + linear_arithmetic='split': 3x3 convolutions and the LightGlue "
+                                  "GEMMs as six bf16 MFMA products per fp32 product (three bf16 planes per operand, fp32 "
+                                  "accumulate); attention stays fp32 MFMA.  fp32-level error, whole parity suite green "
+                                  "(GFC_CONV_MODE=split GFC_LINEAR_MODE=split pytest -m gpu); opt-in, NOT the headline"}
         except Exception as e:  # noqa: BLE001
             split_info = {"value": None, "error": repr(e)[:200]}
     if rank == 0:
@@ -329,7 +334,7 @@ def main():
         }
         if split_info is not None:
             out["experimental_split_conv"] = split_info
-        if args.conv_arithmetic == "split":
+        if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":
             out["dtype"] = "f32 via 3 x bf16 split MFMA in the 3x3 convolutions (experimental), f32 elsewhere"
             out["roofline"]["note"] = "split arithmetic: the stem is not an fp32-MFMA kernel; frac is fp32-equivalent FLOPs / fp32 peak"
         if not args.no_cpu_baseline and world == 1:

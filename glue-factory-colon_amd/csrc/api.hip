@@ -228,11 +228,25 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
   void* att_ws = (char*)hbuf + gfc_align((size_t)R * 512 * 4);
   // scratch is indexed [problem][head][max_n queries]: n_problems * maxn <= R for packed rows
   const size_t att_ws_bytes = ((size_t)n_problems * maxn <= (size_t)R) ? lg_attn_scratch_bytes(R) : 0;
+  // fp32 MFMA GEMM (default) or the experimental split arithmetic for the six large GEMMs of the layer
+  const bool split = p->linear_mode == 1;
+  if (split && (p->s_out_w[l] || p->c_out_w[l] || !p->wqkv_split[l] || !p->s_ffn0_split[l] || !p->s_ffn3_split[l] ||
+                !p->c_qkv_split[l] || !p->c_ffn0_split[l] || !p->c_ffn3_split[l]))
+    return GFC_ERR_INVALID;
+  auto lin = [&](const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w, const void* wsp,
+                 int ldw, const float* bias, const float* resid, const float* rc, const float* rs, int rot_cols, float* y,
+                 int ldy, int n) -> int {
+    if (split)
+      return gfc_linear_split(a0, lda0, k0, a1, lda1, k1, wsp, bias, nullptr, nullptr, 1.f, resid, rc, rs, rot_cols, y, ldy,
+                              R, n, st);
+    return gfc_linear(a0, lda0, k0, a1, lda1, k1, w, ldw, bias, nullptr, nullptr, 1.f, resid, rc, rs, rot_cols, y, ldy, R,
+                      n, st);
+  };
   {
 
     // ---- self block (lightglue.py:151-164) ----
-    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, nullptr, 1.f, nullptr, cosb, sinb,
-                       512, qkv, 768, R, 768, st));
+    GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
+                768));
     GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, n_problems, maxn, 4, 0.125f, att_ws,
                           att_ws_bytes, st));
     // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
@@ -243,14 +257,14 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1s = msg;
     }
-    GFC_TRY(gfc_linear(x, D, D, a1s, D, D, p->s_ffn0_w[l], 512, p->s_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
-                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
+    GFC_TRY(lin(x, D, D, a1s, D, D, p->s_ffn0_w[l], p->s_ffn0_split[l], 512, p->s_ffn0_b[l], nullptr, nullptr, nullptr, 0,
+                hbuf, 512, 512));
     GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->s_ln_g[l], p->s_ln_b[l], st));
-    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], nullptr, nullptr, 1.f, x,
-                       nullptr, nullptr, 0, x, D, R, D, st));
+    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], p->s_ffn3_split[l], 512, p->s_ffn3_b[l], x, nullptr, nullptr,
+                0, x, D, D));
     // ---- cross block (lightglue.py:193-222) ----
-    GFC_TRY(gfc_linear(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, 1.f, nullptr, nullptr,
-                       nullptr, 0, qkv, 512, R, 512, st));
+    GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], p->c_qkv_split[l], D, p->c_qkv_b[l], nullptr, nullptr, nullptr, 0,
+                qkv, 512, 512));
     GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, n_problems, maxn, 4, 0.125f, att_ws,
                           att_ws_bytes, st));
     const float* a1c = ctx;
@@ -259,11 +273,11 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1c = msg;
     }
-    GFC_TRY(gfc_linear(x, D, D, a1c, D, D, p->c_ffn0_w[l], 512, p->c_ffn0_b[l], nullptr, nullptr, 1.f, nullptr,
-                       nullptr, nullptr, 0, hbuf, 512, R, 512, st));
+    GFC_TRY(lin(x, D, D, a1c, D, D, p->c_ffn0_w[l], p->c_ffn0_split[l], 512, p->c_ffn0_b[l], nullptr, nullptr, nullptr, 0,
+                hbuf, 512, 512));
     GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->c_ln_g[l], p->c_ln_b[l], st));
-    GFC_TRY(gfc_linear(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], nullptr, nullptr, 1.f, x,
-                       nullptr, nullptr, 0, x, D, R, D, st));
+    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], p->c_ffn3_split[l], 512, p->c_ffn3_b[l], x, nullptr, nullptr,
+                0, x, D, D));
     }
   return GFC_OK;
 }

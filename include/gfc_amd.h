@@ -248,6 +248,16 @@ typedef struct {
   /* token_confidence.{i}.token.0 (lightglue.py:69-80), i < n_layers-1 */
   const float* token_w[GFC_LG_MAX_LAYERS]; /* [256] */
   const float* token_b[GFC_LG_MAX_LAYERS]; /* [1] */
+  /* EXPERIMENTAL, opt-in: linear_mode = 1 runs the six large GEMMs of every layer (Wqkv, self ffn.0 / ffn.3, cross
+   * to_qk|to_v, cross ffn.0 / ffn.3) as bf16x3-split MFMA products at fp32 accuracy (gfc_linear_split) from weights
+   * packed by gfc_pack_linear_split; needs the folded out_proj layout (s_out_w / c_out_w NULL).  0: fp32 MFMA. */
+  int linear_mode;
+  const void* wqkv_split[GFC_LG_MAX_LAYERS];
+  const void* s_ffn0_split[GFC_LG_MAX_LAYERS];
+  const void* s_ffn3_split[GFC_LG_MAX_LAYERS];
+  const void* c_qkv_split[GFC_LG_MAX_LAYERS];
+  const void* c_ffn0_split[GFC_LG_MAX_LAYERS];
+  const void* c_ffn3_split[GFC_LG_MAX_LAYERS];
 } gfc_lg_params;
 
 size_t gfc_lg_workspace_bytes(int B, int M, int N);
@@ -337,6 +347,13 @@ int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_
 int gfc_pack_conv3x3_split(const float* w_oihw, void* w_split, int cout, int cin, void* stream);
 int gfc_conv3x3_split(const float* x, const void* w_split, const float* bias, const float* scale, const float* shift,
                       float* y, int B, int H, int W, int cin, int cout, int relu, int pool, void* stream);
+/* EXPERIMENTAL, opt-in: gfc_linear in the same split arithmetic.  gfc_pack_linear_split: W [N,K] fp32 (row stride ldw)
+ * -> [N][K/16][3][16] bf16 (3*N*K values); gfc_linear_split: arguments as gfc_linear with the packed weights. */
+int gfc_pack_linear_split(const float* W, int ldw, void* w_split, int N, int K, void* stream);
+int gfc_linear_split(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const void* w_split,
+                     const float* bias, const float* scale, const float* shift, float alpha, const float* residual,
+                     const float* rot_cos, const float* rot_sin, int rot_cols, float* Y, int ldy, int M, int N,
+                     void* stream);
 /* the stem of gfc_sp_stem with conv1b in the split arithmetic (conv1a: fp32 VALU on the halo tile, as there) */
 int gfc_sp_stem_split(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
                       const void* w2_split, const float* b2, const float* s2, const float* t2, float* y, int B, int H,

@@ -290,6 +290,43 @@ def test_linear_plain(m, n, k):
     assert maxerr(run_linear(a, w, b, alpha=0.25), F.linear(a, w, b) / 4) < 1e-5
 
 
+def test_linear_split_accuracy():
+    """Experimental bf16x3-split GEMM: error against float64 of the order of the fp32-MFMA GEMM's, all epilogues."""
+    lib = nat.lib()
+    g = gen(77)
+    m, k0, k1, n = 777, 256, 256, 512
+    a0, a1 = torch.randn((m, k0), generator=g), torch.randn((m, k1), generator=g)
+    w = torch.randn((n, k0 + k1), generator=g) / (k0 + k1) ** 0.5
+    bias = torch.randn((n,), generator=g)
+    resid = torch.randn((m, n), generator=g)
+    cos, sin = torch.rand((m, 64), generator=g), torch.rand((m, 64), generator=g)
+    ws = torch.empty((3 * n * (k0 + k1),), device=DEV, dtype=torch.bfloat16)
+    nat.check(lib.gfc_pack_linear_split(nat.ptr(D(w)), k0 + k1, nat.ptr(ws), n, k0 + k1, st()), "pack")
+    ref = F.linear(torch.cat([a0, a1], 1).double(), w.double(), bias.double())
+
+    def run(split, residual=None, rot=False):
+        y = torch.full((m, n), float("nan"), device=DEV)
+        if residual is not None:
+            y.copy_(residual)
+        args_tail = (nat.ptr(D(bias)), None, None, 1.0, nat.ptr(y) if residual is not None else None,
+                     nat.ptr(D(cos)) if rot else None, nat.ptr(D(sin)) if rot else None, 512 if rot else 0, nat.ptr(y), n, m, n,
+                     st())
+        if split:
+            nat.check(lib.gfc_linear_split(nat.ptr(D(a0)), k0, k0, nat.ptr(D(a1)), k1, k1, nat.ptr(ws), *args_tail), "split")
+        else:
+            nat.check(lib.gfc_linear(nat.ptr(D(a0)), k0, k0, nat.ptr(D(a1)), k1, k1, nat.ptr(D(w)), k0 + k1, *args_tail),
+                      "fp32")
+        torch.cuda.synchronize()
+        return y.double().cpu()
+
+    e_split, e_fp32 = (run(True) - ref).abs().max().item(), (run(False) - ref).abs().max().item()
+    assert e_split < 1e-5 and e_split < 3 * e_fp32 + 1e-6, (e_split, e_fp32)
+    assert (run(True, residual=resid) - (ref + resid.double())).abs().max().item() < 1e-5
+    assert (run(True, rot=True) - run(False, rot=True)).abs().max().item() < 1e-5      # rotary epilogue, same code
+    from parity_utils import record
+    record("linear_split_err", split_max_abs_err=e_split, fp32_mfma_max_abs_err=e_fp32)
+
+
 def test_gemm_tile_variants_via_knob():
     """Every GEMM variant behind GFC_GEMM_TILE (128x256, 128x128, 64x64 with 32/16-deep K tiles, the LDS-DMA kernel)
     passes the linear / batched tests; the knob is read once per process, hence child processes."""

@@ -64,6 +64,35 @@ def bench_gemm():
         report(f"gemm[{os.environ.get('GFC_GEMM_TILE', 'auto')}] {name}", timeit(fn), 2.0 * R * n * (k0 + k1))
 
 
+def bench_gemm_split():
+    """Experimental bf16x3-split GEMM at the LightGlue shapes (TFLOP/s of fp32-equivalent work)."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    R = 65536
+    x = torch.randn((R, 256), device=DEV)
+    msg = torch.randn((R, 256), device=DEV)
+    hbuf = torch.randn((R, 512), device=DEV)
+    cos, sin = torch.rand((R, 64), device=DEV), torch.rand((R, 64), device=DEV)
+    for name, a0, a1, n, k0, k1, rot, res in [("split qkv  N=768 K=256 rotary", x, None, 768, 256, 0, True, False),
+                                              ("split qkv' N=512 K=256", x, None, 512, 256, 0, False, False),
+                                              ("split ffn0 N=512 K=256+256 (concat)", x, msg, 512, 256, 256, False, False),
+                                              ("split ffn3 N=256 K=512 residual", hbuf, None, 256, 512, 0, False, True)]:
+        w = torch.randn((n, k0 + k1), device=DEV) / 16
+        ws = torch.empty((3 * n * (k0 + k1),), device=DEV, dtype=torch.bfloat16)
+        nat.check(lib.gfc_pack_linear_split(nat.ptr(w), k0 + k1, nat.ptr(ws), n, k0 + k1, st), "pack")
+        b = torch.randn((n,), device=DEV)
+        y = torch.empty((R, n), device=DEV)
+        resid = torch.randn((R, n), device=DEV) if res else None
+
+        def fn():
+            nat.check(lib.gfc_linear_split(nat.ptr(a0), a0.shape[1], k0, nat.ptr(a1), 0 if a1 is None else a1.shape[1], k1,
+                                           nat.ptr(ws), nat.ptr(b), None, None, 1.0, nat.ptr(resid),
+                                           nat.ptr(cos) if rot else None, nat.ptr(sin) if rot else None, 512 if rot else 0,
+                                           nat.ptr(y), n, R, n, st), "linear_split")
+
+        report(name, timeit(fn), 2.0 * R * n * (k0 + k1))
+
+
 def bench_gemm_sweep():
     """Fixed vs per-K cost: N = 256, K = 256..2048 (synthetic shapes)."""
     lib = nat.lib()
@@ -224,6 +253,7 @@ if __name__ == "__main__":
         bench_gemm_small()
     if args.only in ("", "split"):
         bench_conv_split()
+        bench_gemm_split()
     if args.only in ("", "conv", "stem"):
         bench_stem()
     if args.only in ("", "conv"):
