@@ -174,6 +174,8 @@ def main():
                          "c4 = configs[3] shape (1024x1024, 2048 kpts) for information")
     ap.add_argument("--joint-extract", type=int, default=1,
                     help="1: run the extractor once on both views' images (2*pairs images per call)")
+    ap.add_argument("--no-experimental", action="store_true",
+                    help="skip the extra `experimental_split_conv` leg (profiling runs: only the default path's kernels)")
     ap.add_argument("--linear-arithmetic", default=None, choices=[None, "fp32", "split"],
                     help="LightGlue GEMMs of the timed path (see --conv-arithmetic)")
     ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split"],
@@ -262,7 +264,8 @@ def main():
 
     # information only: the same steps with the experimental split-bf16 convolutions (opt-in arithmetic, not `value`)
     split_info = None
-    if world == 1 and args.conv_arithmetic is None and args.linear_arithmetic is None and args.workload == "c2":
+    if (world == 1 and args.conv_arithmetic is None and args.linear_arithmetic is None and args.workload == "c2"
+            and not args.no_experimental):
         try:
             ext_s = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K,
                                                 "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True,
