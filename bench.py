@@ -200,7 +200,8 @@ def main():
                                       "nms_radius": 3, "force_num_keypoints": True,
                                       "conv_arithmetic": args.conv_arithmetic}).eval().to(dev)
     mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
-                               "width_confidence": -1, "linear_arithmetic": args.linear_arithmetic}).eval().to(dev)
+                               "width_confidence": -1, "linear_arithmetic": args.linear_arithmetic,
+                               "attention_arithmetic": args.linear_arithmetic}).eval().to(dev)
     if args.workload == "c4":
         H, W, K = 1024, 1024, 2048
         STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * H * W
@@ -271,7 +272,8 @@ def main():
                                                 "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True,
                                                 "conv_arithmetic": "split"}).eval().to(dev)
             mat_s = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
-                                         "width_confidence": -1, "linear_arithmetic": "split"}).eval().to(dev)
+                                         "width_confidence": -1, "linear_arithmetic": "split",
+                                         "attention_arithmetic": "split"}).eval().to(dev)
             with torch.no_grad():
                 for _ in range(args.warmup):
                     step(ext_s, mat_s)
@@ -284,10 +286,11 @@ def main():
             same = (pred_s["matches0"] >= 0).sum().item(), (pred["matches0"] >= 0).sum().item()
             split_info = {"value": round(b * args.steps / dts, 3), "unit": "image-pairs/sec",
                           "ms_per_step": round(dts / args.steps * 1e3, 3), "matches_split_vs_fp32": list(same),
-                          "note": "conv_arithmetic='split' + linear_arithmetic='split': 3x3 convolutions and the LightGlue "
-                                  "GEMMs as six bf16 MFMA products per fp32 product (three bf16 planes per operand, fp32 "
-                                  "accumulate); attention stays fp32 MFMA.  fp32-level error, whole parity suite green "
-                                  "(GFC_CONV_MODE=split GFC_LINEAR_MODE=split pytest -m gpu); opt-in, NOT the headline"}
+                          "note": "conv_arithmetic / linear_arithmetic / attention_arithmetic = 'split': 3x3 convolutions, "
+                                  "the LightGlue GEMMs and the attention products as six bf16 MFMA products per fp32 "
+                                  "product (three bf16 planes per operand, fp32 accumulate, fp32 soft-max).  fp32-level "
+                                  "error, whole parity suite green (GFC_CONV_MODE=split GFC_LINEAR_MODE=split "
+                                  "GFC_ATTN_MODE=split pytest -m gpu); opt-in, NOT the headline"}
         except Exception as e:  # noqa: BLE001
             split_info = {"value": None, "error": repr(e)[:200]}
     if rank == 0:

@@ -44,7 +44,7 @@ class LgParams(Structure):
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in _LG_ARRAYS]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in ("final_proj_w", "final_proj_b", "matchability_w",
                                                                "matchability_b", "token_w", "token_b")]
-                + [("linear_mode", c_int)]
+                + [("linear_mode", c_int), ("attention_mode", c_int)]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in ("wqkv_split", "s_ffn0_split", "s_ffn3_split",
                                                                "c_qkv_split", "c_ffn0_split", "c_ffn3_split")])
 
@@ -98,6 +98,8 @@ SIGNATURES = {
     "gfc_pack_linear_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "gfc_linear_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gfc_attention_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                    c_int, c_int, c_float, c_void_p]),
     "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_refine_keypoints": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "gfc_sp_mask_scores": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p] * 2),

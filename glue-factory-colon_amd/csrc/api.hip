@@ -233,6 +233,12 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
   if (split && (p->s_out_w[l] || p->c_out_w[l] || !p->wqkv_split[l] || !p->s_ffn0_split[l] || !p->s_ffn3_split[l] ||
                 !p->c_qkv_split[l] || !p->c_ffn0_split[l] || !p->c_ffn3_split[l]))
     return GFC_ERR_INVALID;
+  // attention: fp32 MFMA (default; with its key split for small problem sets) or the experimental split arithmetic
+  const bool att_split = p->attention_mode == 1 && (long long)n_problems * 4 * ((maxn + 127) / 128) >= 512;
+  auto attn = [&](const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* probs) -> int {
+    if (att_split) return gfc_attention_split(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, st);
+    return gfc_attention(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, att_ws, att_ws_bytes, st);
+  };
   auto lin = [&](const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w, const void* wsp,
                  int ldw, const float* bias, const float* resid, const float* rc, const float* rs, int rot_cols, float* y,
                  int ldy, int n) -> int {
@@ -247,8 +253,7 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
     // ---- self block (lightglue.py:151-164) ----
     GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
                 768));
-    GFC_TRY(gfc_attention(qkv, 768, qkv + 256, 768, qkv + 512, 768, ctx, D, self_p, n_problems, maxn, 4, 0.125f, att_ws,
-                          att_ws_bytes, st));
+    GFC_TRY(attn(qkv, 768, qkv + 256, 768, qkv + 512, 768, self_p));
     // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
     // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
     const float* a1s = ctx;
@@ -265,8 +270,7 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
     // ---- cross block (lightglue.py:193-222) ----
     GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], p->c_qkv_split[l], D, p->c_qkv_b[l], nullptr, nullptr, nullptr, 0,
                 qkv, 512, 512));
-    GFC_TRY(gfc_attention(qkv, 512, qkv, 512, qkv + 256, 512, ctx, D, cross_p, n_problems, maxn, 4, 0.125f, att_ws,
-                          att_ws_bytes, st));
+    GFC_TRY(attn(qkv, 512, qkv, 512, qkv + 256, 512, cross_p));
     const float* a1c = ctx;
     if (p->c_out_w[l]) {
       GFC_TRY(gfc_linear(ctx, D, D, nullptr, 0, 0, p->c_out_w[l], D, p->c_out_b[l], nullptr, nullptr, 1.f, nullptr,

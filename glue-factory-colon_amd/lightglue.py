@@ -76,6 +76,7 @@ class LightGlue(nn.Module):
         "input_dim": 256,
         "add_scale_ori": False,
         "linear_arithmetic": None,  # MI355X addition: None = fp32 MFMA (or $GFC_LINEAR_MODE); "split" = experimental
+        "attention_arithmetic": None,  # likewise for self / cross attention ($GFC_ATTN_MODE)
         "descriptor_dim": 256,
         "n_layers": 9,
         "num_heads": 4,
@@ -169,6 +170,11 @@ class LightGlue(nn.Module):
                 raise ValueError("linear_arithmetic 'split' needs fold_out_proj")
             mode = "fp32"  # requested through the environment only: modules with separate out_proj GEMMs keep fp32
         p.linear_mode = 1 if mode == "split" else 0
+        amode = (conf.attention_arithmetic if conf.attention_arithmetic is not None
+                 else os.environ.get("GFC_ATTN_MODE", "fp32"))
+        if amode not in ("fp32", "split"):
+            raise ValueError(f"attention_arithmetic {amode!r}: 'fp32' or 'split'")
+        p.attention_mode = 1 if amode == "split" else 0
         lib, st = nat.lib(), nat.stream_ptr(device)
 
         def split(ptr_attr, i, w):

@@ -252,6 +252,9 @@ typedef struct {
    * to_qk|to_v, cross ffn.0 / ffn.3) as bf16x3-split MFMA products at fp32 accuracy (gfc_linear_split) from weights
    * packed by gfc_pack_linear_split; needs the folded out_proj layout (s_out_w / c_out_w NULL).  0: fp32 MFMA. */
   int linear_mode;
+  /* EXPERIMENTAL, opt-in: attention_mode = 1 runs self / cross attention through gfc_attention_split when the problem
+   * set fills the chip (small sets keep the fp32 kernel with its key split).  0: fp32 MFMA. */
+  int attention_mode;
   const void* wqkv_split[GFC_LG_MAX_LAYERS];
   const void* s_ffn0_split[GFC_LG_MAX_LAYERS];
   const void* s_ffn3_split[GFC_LG_MAX_LAYERS];
@@ -354,6 +357,10 @@ int gfc_linear_split(const float* A0, int lda0, int K0, const float* A1, int lda
                      const float* bias, const float* scale, const float* shift, float alpha, const float* residual,
                      const float* rot_cos, const float* rot_sin, int rot_cols, float* Y, int ldy, int M, int N,
                      void* stream);
+/* EXPERIMENTAL, opt-in: gfc_attention in the split arithmetic (Q.K^T and P.V as six bf16 MFMA products per fp32
+ * product; soft-max in fp32).  Same arguments without the key-split scratch. */
+int gfc_attention_split(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                        const int32_t* problems, int n_problems, int max_nq, int heads, float scale, void* stream);
 /* the stem of gfc_sp_stem with conv1b in the split arithmetic (conv1a: fp32 VALU on the halo tile, as there) */
 int gfc_sp_stem_split(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
                       const void* w2_split, const float* b2, const float* s2, const float* t2, float* y, int B, int H,

@@ -140,7 +140,7 @@ def test_split_conv_arithmetic_passes_the_model_parity_tests():
     import subprocess
     import sys
 
-    env = dict(os.environ, GFC_CONV_MODE="split", GFC_LINEAR_MODE="split")   # split GEMMs in LightGlue as well
+    env = dict(os.environ, GFC_CONV_MODE="split", GFC_LINEAR_MODE="split", GFC_ATTN_MODE="split")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p",
                         "no:cacheprovider", "-k", "superpoint_open or superpoint_official or pipeline_golden or "
                         "vga_1024 or specular or refinement or large_2048 or lightglue_golden or lightglue_layer0 or "

@@ -432,6 +432,48 @@ def test_attention(shapes, use_ws):
             assert torch.isnan(o[r + nq:r + max(nq, nk)]).all()  # rows of other problems untouched
 
 
+def test_attention_split_accuracy():
+    """Experimental split-arithmetic attention against a float64 soft-max attention: error of the order of the
+    fp32-MFMA kernel's; ragged problems (tails, different n_q / n_kv) included."""
+    lib = nat.lib()
+    g = gen(123)
+    sizes = [(200, 333), (333, 200), (128, 64), (70, 1000)]
+    rows = sum(max(a, b) for a, b in sizes) * 2
+    qkv = torch.randn((rows, 768), generator=g)
+    qkv[:, :512] *= 1.7
+    probs, r = [], 0
+    for nq, nk in sizes:
+        probs.append([r, nq, r + nq, nk])
+        r += nq + nk
+    pt = torch.tensor(probs, dtype=torch.int32)
+    heads, scale = 4, 0.125
+    ref = torch.zeros((rows, 256), dtype=torch.float64)
+    for q0, nq, k0, nk in probs:
+        for hh in range(heads):
+            qq = qkv[q0:q0 + nq, 64 * hh:64 * hh + 64].double()
+            kk = qkv[k0:k0 + nk, 256 + 64 * hh:256 + 64 * hh + 64].double()
+            vv = qkv[k0:k0 + nk, 512 + 64 * hh:512 + 64 * hh + 64].double()
+            ref[q0:q0 + nq, 64 * hh:64 * hh + 64] = torch.softmax(qq @ kk.T * scale, -1) @ vv
+    qd = D(qkv)
+    errs = {}
+    for name in ("fp32", "split"):
+        o = torch.zeros((rows, 256), device=DEV)
+        args = (nat.ptr(qd), 768, nat.c_void_p(qd.data_ptr() + 256 * 4), 768, nat.c_void_p(qd.data_ptr() + 512 * 4), 768,
+                nat.ptr(o), 256, nat.ptr(D(pt)), len(probs), max(a for a, _ in sizes), heads, scale)
+        if name == "fp32":
+            nat.check(lib.gfc_attention(*args, None, 0, st()), "attention")
+        else:
+            nat.check(lib.gfc_attention_split(*args, st()), "attention_split")
+        torch.cuda.synchronize()
+        e = 0.0
+        for q0, nq, _, _ in probs:
+            e = max(e, (o[q0:q0 + nq].double().cpu() - ref[q0:q0 + nq]).abs().max().item())
+        errs[name] = e
+    assert errs["split"] < 1e-5 and errs["split"] < 3 * errs["fp32"] + 1e-6, errs
+    from parity_utils import record
+    record("attention_split_err", split_max_abs_err=errs["split"], fp32_mfma_max_abs_err=errs["fp32"])
+
+
 def test_attention_peaky_rows():
     """A spiked key forces the running-max rescale branch at a chosen tile (online softmax)."""
     lib = nat.lib()

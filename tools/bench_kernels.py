@@ -64,6 +64,24 @@ def bench_gemm():
         report(f"gemm[{os.environ.get('GFC_GEMM_TILE', 'auto')}] {name}", timeit(fn), 2.0 * R * n * (k0 + k1))
 
 
+def bench_attn_split():
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    B, K = 32, 1024
+    R = 2 * B * K
+    qkv = torch.randn((R, 768), device=DEV)
+    o = torch.empty((R, 256), device=DEV)
+    self_p = torch.tensor([[i * K, K, i * K, K] for i in range(2 * B)], dtype=torch.int32, device=DEV)
+    cross_p = torch.tensor([[i * K, K, (B + i) * K, K] for i in range(B)]
+                           + [[(B + i) * K, K, i * K, K] for i in range(B)], dtype=torch.int32, device=DEV)
+    for name, pt in (("split self attention 64 x (1024x1024), 4 heads", self_p), ("split cross attention (2 directions)", cross_p)):
+        def fn():
+            nat.check(lib.gfc_attention_split(nat.ptr(qkv), 768, nat.c_void_p(qkv.data_ptr() + 256 * 4), 768,
+                                              nat.c_void_p(qkv.data_ptr() + 512 * 4), 768, nat.ptr(o), 256, nat.ptr(pt),
+                                              2 * B, K, 4, 0.125, st), "attention_split")
+        report(name, timeit(fn), 4.0 * 2 * B * 4 * K * K * 64)
+
+
 def bench_gemm_split():
     """Experimental bf16x3-split GEMM at the LightGlue shapes (TFLOP/s of fp32-equivalent work)."""
     lib = nat.lib()
@@ -254,6 +272,7 @@ if __name__ == "__main__":
     if args.only in ("", "split"):
         bench_conv_split()
         bench_gemm_split()
+        bench_attn_split()
     if args.only in ("", "conv", "stem"):
         bench_stem()
     if args.only in ("", "conv"):
