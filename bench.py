@@ -175,13 +175,13 @@ def main():
     ap.add_argument("--joint-extract", type=int, default=1,
                     help="1: run the extractor once on both views' images (2*pairs images per call)")
     ap.add_argument("--no-experimental", action="store_true",
-                    help="skip the extra `experimental_split_conv` leg (profiling runs: only the default path's kernels)")
+                    help="skip the extra `experimental_split_arithmetic` leg (profiling runs: only the default path's kernels)")
     ap.add_argument("--linear-arithmetic", default=None, choices=[None, "fp32", "split"],
                     help="LightGlue GEMMs of the timed path (see --conv-arithmetic)")
     ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split"],
                     help="3x3 convolutions of the timed path: fp32 MFMA (default) or the experimental bf16x3-split MFMA "
                          "products at fp32 accuracy; the default run additionally reports the split variant as "
-                         "`experimental_split_conv` (N = 1 only)")
+                         "`experimental_split_arithmetic` (N = 1 only)")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU work: exercise only the multi-process plumbing (rendezvous, barriers, max-reduce, "
                          "final gather, JSON) on gloo with a dummy step; never a measurement")
@@ -339,7 +339,7 @@ def main():
                          "flops_per_launch": flops_per_launch},
         }
         if split_info is not None:
-            out["experimental_split_conv"] = split_info
+            out["experimental_split_arithmetic"] = split_info
         if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":
             out["dtype"] = "f32 via 3 x bf16 split MFMA in the 3x3 convolutions (experimental), f32 elsewhere"
             out["roofline"]["note"] = "split arithmetic: the stem is not an fp32-MFMA kernel; frac is fp32-equivalent FLOPs / fp32 peak"
