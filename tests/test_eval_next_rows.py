@@ -93,6 +93,44 @@ def test_export_predictions_contract(tmp_path, monkeypatch):
     assert half["v_seq/2.ppm"]["keypoints0"].dtype == np.float16 and half["v_seq/2.ppm"]["matches0"].dtype == np.int64
 
 
+def test_cache_loader_round_trip(tmp_path):
+    """export_predictions divides key points by `scales`, CacheLoader multiplies them back in
+    (export_predictions.py:73-79, cache_loader.py:145-154): exported per-image features come back unchanged, padded
+    to a common length and batched."""
+    from glue_factory_colon_amd.cache_loader import CacheLoader
+
+    def feats(n):
+        g = torch.Generator().manual_seed(n)
+        return {"keypoints": torch.rand((1, n, 2), generator=g) * 100, "keypoint_scores": torch.rand((1, n), generator=g),
+                "descriptors": torch.rand((1, n, 8), generator=g)}
+
+    class Fake(torch.nn.Module):
+        def forward(self, data):
+            return feats(5 if data["name"][0].endswith("0.ppm") else 3)
+
+    scales = torch.tensor([[0.5, 0.25]])
+
+    def loader():
+        for i in range(2):
+            yield {"name": [f"s/{i}.ppm"], "scales": scales}
+
+    path = ep.export_predictions(loader(), Fake(), tmp_path / "feats.npz")
+    stored = ep.load_predictions(path)["s/0.ppm"]["keypoints"]
+    assert np.allclose(stored, (feats(5)["keypoints"][0] / scales[0]).numpy(), atol=1e-5)   # original-image pixels
+    cl = CacheLoader({"path": str(path), "add_data_path": False, "padding_fn": "pad_local_features", "padding_length": 6})
+    assert cl.is_initialized()
+    out = cl({"name": ["s/0.ppm", "s/1.ppm"], "scales": scales.repeat(2, 1)})
+    assert out["keypoints"].shape == (2, 6, 2) and out["descriptors"].shape == (2, 6, 8)
+    assert torch.allclose(out["keypoints"][0, :5], feats(5)["keypoints"][0], atol=1e-4)
+    assert torch.allclose(out["keypoints"][1, :3], feats(3)["keypoints"][0], atol=1e-4)
+    assert (out["keypoint_scores"][1, 3:] == 0).all()                                          # zero-padded scores
+    one = CacheLoader({"path": str(path), "add_data_path": False, "collate": False, "data_keys": ["keypoint_scores"]})(
+        {"name": ["s/1.ppm"], "scales": scales})
+    assert set(one) == {"keypoint_scores"} and one["keypoint_scores"].shape == (3,)
+    with pytest.raises(NotImplementedError):
+        CacheLoader({"path": str(path), "padding_fn": "lambda p, n: p"})
+
+
 @pytest.mark.gpu
 def test_match_metrics_gpu_vs_oracle_and_known_answers():
     from glue_factory_colon_amd import eval_utils
