@@ -19,6 +19,7 @@ ALIASES = {
     "matchers.nearest_neighbor_matcher": "nearest_neighbor_matcher",
     "nearest_neighbor_matcher": "nearest_neighbor_matcher",
     "two_view_pipeline": "two_view_pipeline",
+    "cache_loader": "cache_loader",
 }
 
 
