@@ -164,7 +164,7 @@ static LgPlan lg_plan(int B, int M, int N) {
   const size_t asg = gfc_lg_assign_workspace_bytes(B, M, N);
   if (asg > stage) stage = asg;
   p.qkv = take(stage);
-  p.msg = take(p.R * 2 * 4);  // packed key points for the rotary tables
+  p.msg = take(p.R * 4 * 4);  // packed key points [R][2] (+ scales / orientations [R][2]) for the rotary tables
   p.cosb = take(p.R * 64 * 4);
   p.sinb = take(p.R * 64 * 4);
   p.tables = take((size_t)B * (2 * 4 * 2 + 2 + 2 + 4) * 4 + 256);

@@ -155,6 +155,46 @@ def test_split_conv_arithmetic_passes_the_model_parity_tests():
     assert 0 < d < 1e-5, d
 
 
+def test_results_do_not_depend_on_workspace_contents(golden):
+    """The scratch buffers are caller-owned and uninitialised: poisoning them (0x00 vs 0xFF bytes = NaNs) before a
+    call must not change any output.  (Found a real bug once: the scale / orientation scratch of add_scale_ori
+    overlapped the rotary table it feeds.)"""
+    def poison(module, byte):
+        for m in module.modules():
+            for holder in (m, getattr(m, "_runner", None)):
+                for name in ("_ws", "ws", "ws_sel"):
+                    w = getattr(holder, name, None) if holder is not None else None
+                    if w is not None and getattr(w, "buf", None) is not None:
+                        w.buf.fill_(byte)
+
+    g = golden("scale_ori")
+    sd = weights.lightglue_state_dict(0, add_scale_ori=True)
+    mat = lightglue.LightGlue({"weights": None, "filter_threshold": 0.1, "add_scale_ori": True}).eval()
+    mat.load_state_dict(sd, strict=False)
+    mat = mat.to(DEV)
+    data = {k: g[k].to(DEV) for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1", "scales0", "scales1",
+                                       "oris0", "oris1")}
+    data["view0"] = data["view1"] = {"image_size": g["image_size"].to(DEV)}
+    ext = spo(max_num_keypoints=256, detection_threshold=0.0, nms_radius=3)
+    img = synthetic.synthetic_images(1, 200, 264, seed=12).to(DEV)
+    adaptive = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": 0.95,
+                                    "width_confidence": 0.99}).eval().to(DEV)
+    d1 = {"keypoints0": g["keypoints0"][:1].to(DEV), "keypoints1": g["keypoints1"][:1].to(DEV),
+          "descriptors0": g["descriptors0"][:1].to(DEV), "descriptors1": g["descriptors1"][:1].to(DEV),
+          "view0": {"image_size": g["image_size"][:1].to(DEV)}, "view1": {"image_size": g["image_size"][:1].to(DEV)}}
+    runs = []
+    for byte in (None, 0x00, 0xFF):
+        if byte is not None:
+            for mod in (mat, ext, adaptive):
+                poison(mod, byte)
+        o, e, a = mat(data), ext({"image": img}), adaptive(d1)
+        runs.append([o["matches0"], o["matching_scores0"], o["log_assignment"], e["keypoints"], e["keypoint_scores"],
+                     e["descriptors"], a["matches0"], a["matching_scores0"]])
+    for r in runs[1:]:
+        for x, y in zip(r, runs[0]):
+            assert torch.equal(x, y)
+
+
 def test_run_to_run_determinism_vga_batch():
     """No atomics-ordered arithmetic, no races in the LDS pipelines / persistent hand-over: the same batch gives
     bit-identical key points, descriptors, matches and scores run after run (also interleaved with other shapes)."""
