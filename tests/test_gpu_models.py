@@ -215,8 +215,11 @@ def test_run_to_run_determinism_vga_batch():
 
     ref = [t.clone() for t in run()]
     other = synthetic.synthetic_images(1, 200, 264, seed=1).to(DEV)
-    for _ in range(3):
+    for it in range(3):
         ext({"image": other, "image_size": torch.tensor([[264.0, 200.0]], device=DEV)})  # different shape in between
+        for w in (ext._runner.ws, ext._runner.ws_sel, mat._ws):                           # and poisoned scratch
+            if w.buf is not None:
+                w.buf.fill_(0xFF if it % 2 else 0x00)
         for a, b in zip(run(), ref):
             assert torch.equal(a, b)
 
