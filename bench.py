@@ -2,7 +2,9 @@
 """Benchmark of the SuperPoint + LightGlue hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: either launched by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+     (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), or as the plain command above: the parent then
+     starts the N rank processes itself -- before making any GPU call -- and relays rank 0's JSON line)
 
 Metric (BASELINE.json): image-pairs/sec, SuperPoint + LightGlue, 1024 keypoints, 640x480.
 One "step" = one pass of the hot path over one batch of synthetic pairs resident in HBM:
@@ -19,6 +21,8 @@ convolution conv1a+conv1b+pool, timed live with HIP events around each launch in
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -126,6 +130,62 @@ def torch_eager_same_gpu(dev, n_pairs: int = 16, iters: int = 4):
             "sample": f"{iters} iterations of {n_pairs} VGA pairs, oracle tensors on cuda:0 (PyTorch-ROCm eager fp32)"}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) as children with the
+    torchrun environment, wait for them and relay rank 0's stdout (the one JSON line).  The parent makes no GPU
+    call (nothing before this point touches HIP), it only waits.  Returns the exit code for the parent."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    for line in (out0 or "").splitlines():
+        # rank 0's stdout carries the ONE JSON line; anything a backend library printed there goes to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: rank(s) failed: {bad}", file=sys.stderr)
+        return bad[0][1] if bad[0][1] > 0 else 1
+    return 0
+
+
+def self_check(v0, v1, p0, p1, pred, idx=0):
+    """Pair `idx` of the LAST timed step against the CPU oracle (outside the timed region): what was measured is
+    also what is correct.  Same comparison as tests/test_gpu_batch32.py."""
+    from oracle import lightglue as olg
+    from oracle import superpoint as osp
+
+    imgs = torch.cat([v0[idx:idx + 1], v1[idx:idx + 1]], 0).cpu()
+    o = osp.extract(weights.superpoint_open_state_dict(0), imgs, "open", nms_radius=3, max_num_keypoints=K,
+                    detection_threshold=0.0)
+    okp, ode = torch.stack(o["keypoints"]), torch.stack(o["descriptors"])
+    size = torch.tensor([[float(W), float(H)]])
+    ref = olg.match(weights.lightglue_state_dict(0), okp[:1], okp[1:], ode[:1], ode[1:], size, size,
+                    filter_threshold=0.1)
+
+    def pairs(kp0, kp1, m0, s0):
+        kp0, kp1, m0, s0 = kp0.cpu(), kp1.cpu(), m0.cpu(), s0.cpu()
+        return {(*kp0[a].tolist(), *kp1[int(m0[a])].tolist()): float(s0[a])
+                for a in (m0 >= 0).nonzero().flatten().tolist()}
+
+    mine = pairs(p0["keypoints"][idx], p1["keypoints"][idx], pred["matches0"][idx], pred["matching_scores0"][idx])
+    theirs = pairs(okp[0], okp[1], ref["matches0"][0], ref["matching_scores0"][0])
+    common = set(mine) & set(theirs)
+    kp_same = all(set(map(tuple, p["keypoints"][idx].cpu().tolist())) == set(map(tuple, okp[i].tolist()))
+                  for i, p in enumerate((p0, p1)))
+    return {"pair": idx, "keypoint_sets_equal": bool(kp_same), "pairs_equal": set(mine) == set(theirs),
+            "matches": len(mine), "oracle_matches": len(theirs), "pairs_common": len(common),
+            "score_err": max((abs(mine[q] - theirs[q]) for q in common), default=0.0),
+            "checker": "oracle/ (PyTorch-CPU restatement of the reference path)"}
+
+
 def rehearse_cpu(args):
     """Same control flow as main() around a dummy step, on gloo / CPU tensors (tests/test_host_cpu.py)."""
     rank, world, _ = sharding.init_from_env("gloo")
@@ -167,6 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=32, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-self-check", action="store_true",
+                    help="skip the oracle check of pair 0 of the last timed step (after the timed region)")
     ap.add_argument("--cpu-pairs", type=int, default=2)
     ap.add_argument("--cpu-iters", type=int, default=8)
     ap.add_argument("--workload", default="c2", choices=["c2", "c4"],
@@ -187,11 +249,14 @@ def main():
                          "final gather, JSON) on gloo with a dummy step; never a measurement")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: this process becomes the parent of the N ranks (it has made no GPU call and makes none)
+        raise SystemExit(spawn_ranks(args.gpus))
     if args.rehearse_cpu:
         return rehearse_cpu(args)
     rank, world, local = sharding.init_from_env("nccl")
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nat.lib()  # fail loudly if the HIP library is missing
@@ -324,6 +389,7 @@ def main():
                        "parallelism": f"dp{world} (pairs sharded, one final gather)",
                        "weights": "name-seeded seed 0 (no network)", "mean_matches_per_pair": round(mean_matches, 1),
                        "pairs_gathered": n_pairs_total, "extractor_calls_per_step": 1 if args.joint_extract else 2, "final_gather_ms": round(gather_ms, 3),
+                       "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true, 16, false> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -343,6 +409,11 @@ def main():
         if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":
             out["dtype"] = "f32 via 3 x bf16 split MFMA in the 3x3 convolutions (experimental), f32 elsewhere"
             out["roofline"]["note"] = "split arithmetic: the stem is not an fp32-MFMA kernel; frac is fp32-equivalent FLOPs / fp32 peak"
+        if args.workload == "c2" and not args.no_self_check:
+            try:
+                out["self_check"] = self_check(v0, v1, p0, p1, pred)
+            except Exception as e:  # noqa: BLE001
+                out["self_check"] = {"pairs_equal": None, "error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)
             if args.workload == "c2":

@@ -269,7 +269,7 @@ extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, c
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldo % 4) return GFC_ERR_INVALID;
   // tuning knob (tools/bench_kernels.py): GFC_ATTN_CFG = 1: 2 q-tiles/wave, 4 waves (256 queries / workgroup)
   //                                                      2: 1 q-tile/wave, 4 waves (128);  3: 1 q-tile, 2 waves (64)
-  static const int forced = [] { const char* e = getenv("GFC_ATTN_CFG"); return e ? atoi(e) : 0; }();
+  const int forced = gfc_knobs().attn_cfg;
   auto wgs = [&](int aq) { return (long long)((max_nq + aq - 1) / aq) * heads * n_problems; };
   // the largest query block that still fills the chip twice over (256 CUs x 2 workgroups)
   // (cfg 3, 64 queries per 2-wave workgroup, measured no faster than cfg 2 at batch 1: knob only)
@@ -279,7 +279,7 @@ extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, c
   const int4* pt = reinterpret_cast<const int4*>(problems);
   // key split for small problem sets (batch 1..2): few 128-query blocks cannot fill 1024 SIMDs, so each block's
   // keys are shared out over up to 8 workgroups and a tiny merge kernel combines the partial soft-maxes
-  static const int forced_split = [] { const char* e = getenv("GFC_ATTN_SPLIT"); return e ? atoi(e) : 0; }();
+  const int forced_split = gfc_knobs().attn_split;
   int ksplit = 1;
   if (cfg == 2 && ws != nullptr) {
     const long long w = wgs(128);

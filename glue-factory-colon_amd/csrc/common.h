@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/gfc_amd.h"
+#include "runtime.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -463,12 +463,8 @@ extern "C" int gfc_conv3x3(const float* x, const float* w_packed, const float* b
 template <bool POOL, bool STEM, int KC, bool PERSIST>
 static int launch_conv_t(const ConvArgs& a, dim3 grid, hipStream_t st) {
   const size_t lds = (size_t)(CH * CH * (KC + 4) + 2 * CNB * (KC + 4) + (STEM ? CIM * CIM + 768 : 0)) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute((const void*)conv3x3_mfma_kernel<POOL, STEM, KC, PERSIST>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
+  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)conv3x3_mfma_kernel<POOL, STEM, KC, PERSIST>, lds, lds_ok);
   hipLaunchKernelGGL((conv3x3_mfma_kernel<POOL, STEM, KC, PERSIST>), grid, dim3(256), lds, st, a);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
@@ -477,19 +473,14 @@ static int launch_conv_t(const ConvArgs& a, dim3 grid, hipStream_t st) {
 static int launch_conv(ConvArgs a, bool pool, bool stem, hipStream_t st) {
   a.tiles_x = (a.W + CT - 1) / CT;
   a.tiles_y = (a.H + CT - 1) / CT;
-  static const int ncu = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
+  const int ncu = gfc_device_cus();
   // Variant per layer kind (same-box A/B, tools/ab_build.sh + tools/bench_kernels.py --only conv, 32 VGA images):
   //  * pooled layers and the stem: 16-channel LDS chunks (36 KB: three workgroups per CU), one workgroup per item
   //    (persistent workgroups cost the third resident workgroup in registers: stem -1.5 %, conv2b -1 %);
   //  * un-pooled layers: 32-channel chunks, persistent workgroups (+1.5..2 %; small grids such as conv4a at
   //    60x80 +16 %, because two resident workgroups per CU then share the items evenly).
   // GFC_CONV_KC=32|16 and GFC_CONV_PERSIST=0|1 force a variant.
-  static const int forced_kc = [] { const char* e = getenv("GFC_CONV_KC"); return e ? atoi(e) : 0; }();
-  static const int forced_p = [] { const char* e = getenv("GFC_CONV_PERSIST"); return e ? atoi(e) : -1; }();
+  const int forced_kc = gfc_knobs().conv_kc, forced_p = gfc_knobs().conv_persist;
   const int kc = forced_kc ? forced_kc : (pool ? 16 : 32);
   const bool persist = forced_p >= 0 ? forced_p != 0 : !pool;
   const long long nitems = (long long)a.tiles_x * a.tiles_y * a.B * (a.cout / CNB);

@@ -558,12 +558,8 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   // K-loop buffers, or the per-wave transpose patches of the rotary / residual epilogue if those are larger
   constexpr size_t kloop = (size_t)2 * (BM + BN) * (BK + 4), patches = (size_t)2 * NW * 32 * (32 * MT + 4);
   const size_t lds = (kloop > patches ? kloop : patches) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<NW, MT, BK>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
+  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_nt_kernel<NW, MT, BK>, lds, lds_ok);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
   hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK>), grid, dim3(128 * NW), lds, st, g);
   GFC_LAUNCH_CHECK();
@@ -573,7 +569,7 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
 static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   // tuning knob (tools/bench_kernels.py): GFC_GEMM_TILE=1 (128x256) | 2 (128x128) | 3 (64x64) | 4 (128x128, K tile 16)
   // | 5 (64x64, K tile 16)
-  static const int forced = [] { const char* e = getenv("GFC_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const int forced = gfc_knobs().gemm_tile;
   auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
   int choice = forced;
   if (!choice) {

@@ -226,11 +226,8 @@ static int launch_nms(const float* heat, int B, int H, int W, int border, const 
                       float cand_thr, unsigned long long* cand, int* cand_count, hipStream_t st) {
   constexpr int R = NT + 10 * RAD, RS = R | 1;
   const size_t lds = (size_t)R * RS * (3 * sizeof(float) + 2);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)nms_kernel<RAD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
+  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)nms_kernel<RAD>, lds, lds_ok);
   dim3 grid(((W + NT - 1) / NT) * ((H + NT - 1) / NT), B);
   hipLaunchKernelGGL(nms_kernel<RAD>, grid, dim3(1024), lds, st, heat, H, W, border, valid_wh, out, cand_thr, cand,
                      cand_count);

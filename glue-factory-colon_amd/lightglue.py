@@ -254,11 +254,15 @@ class LightGlue(nn.Module):
         b, m, _ = kpts0.shape
         b, n, _ = kpts1.shape
         device = kpts0.device
-        # like the reference (lightglue.py:430-434) the image sizes come from the views
-        size0 = data["view0"].get("image_size")
-        size1 = data["view1"].get("image_size")
-        if size0 is None or size1 is None:
-            raise NotImplementedError("view0/view1 must carry image_size")
+        # like the reference (lightglue.py:430-434) the image sizes come from the views; a view without
+        # `image_size` normalises by the extent of its own key points (normalize_keypoints, lightglue.py:31-32).
+        # (The reference leaves size0/size1 unbound when a view is absent; here that is treated like a missing size.)
+        size0 = data.get("view0", {}).get("image_size")
+        size1 = data.get("view1", {}).get("image_size")
+        if size0 is None and m > 0:
+            size0 = 1 + kpts0.float().amax(-2) - kpts0.float().amin(-2)
+        if size1 is None and n > 0:
+            size1 = 1 + kpts1.float().amax(-2) - kpts1.float().amin(-2)
         desc0 = data["descriptors0"].contiguous().float()
         desc1 = data["descriptors1"].contiguous().float()
         assert desc0.shape[-1] == conf.input_dim

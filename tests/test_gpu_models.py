@@ -422,6 +422,21 @@ def test_nn_matcher_golden(golden):
         nnm.NearestNeighborMatcher({}).eval()({"descriptors0": data["descriptors0"]})
 
 
+def test_lightglue_without_image_size(golden):
+    """Views without `image_size` (or no views at all): key points are normalised by their own extent
+    (normalize_keypoints, lightglue.py:31-32) -- against the oracle, matches bit-exact."""
+    g = golden("lightglue")
+    m = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+    d = lg_data(g)
+    ref = olg.match(weights.lightglue_state_dict(0), g["keypoints0"], g["keypoints1"], g["descriptors0"],
+                    g["descriptors1"], None, None, filter_threshold=0.1)
+    for views in ({"view0": {}, "view1": {}}, {}):
+        pred = m({**{k: v for k, v in d.items() if not k.startswith("view")}, **views})
+        assert torch.equal(pred["matches0"].cpu(), ref["matches0"]) and torch.equal(pred["matches1"].cpu(), ref["matches1"])
+        assert maxerr(pred["matching_scores0"], ref["matching_scores0"]) < TOL
+    assert not torch.equal(ref["matches0"], g["b2_matches0"])  # and it is a different normalisation
+
+
 def test_lightglue_empty_set():
     m = lightglue.LightGlue({"weights": "synthetic"}).eval().to(DEV)
     size = torch.tensor([[64.0, 48.0]], device=DEV)

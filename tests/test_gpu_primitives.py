@@ -364,12 +364,29 @@ def test_gemm_tile_variants_via_knob():
     import subprocess
     import sys
 
-    for tile in (1, 2, 3, 5, 6, 7):
+    # 4 = gemm_nt_kernel<2,2,16>, the variant large batches (bench.py: 32 pairs) dispatch to by default
+    for tile in (1, 2, 3, 4, 5, 6, 7):
         env = dict(os.environ, GFC_GEMM_TILE=str(tile))
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
                             "-k", "linear_plain or linear_concat or linear_rotary or batched_nt", "-p", "no:cacheprovider"],
                            capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
         assert r.returncode == 0, (tile, r.stdout[-800:], r.stderr[-400:])
+
+
+def test_attention_variants_via_knob():
+    """attention_kernel<2,4> (GFC_ATTN_CFG=1: two 32-query tiles per wave, 256 queries per workgroup -- what a
+    32-pair batch dispatches to) and <1,2> (cfg 3) on the ragged shapes of test_attention (n_q not a multiple of
+    256, n_q != n_kv, query tails) and on the spiked-key case; the knob is read once per process."""
+    import subprocess
+    import sys
+
+    for cfg in (1, 3):
+        env = dict(os.environ, GFC_ATTN_CFG=str(cfg))
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
+                            "-k", "(test_attention and not split and not variants and not natural) or cross_attention",
+                            "-p", "no:cacheprovider"],
+                           capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, (cfg, r.stdout[-800:], r.stderr[-400:])
 
 
 def test_linear_concat_residual_affine():
@@ -421,6 +438,75 @@ def test_batched_nt():
     ref = torch.einsum("bmd,bnd->bmn", a.cpu(), c.cpu())
     assert maxerr(y[:, :m, :n], ref) < 5e-5
     assert (y[:, m, :] == 7).all() and (y[:, :, n] == 7).all()  # border untouched
+
+
+def _ref64(fn, *tensors):
+    """Reference in float64 on the device (plain torch; rocBLAS dgemm), result rounded to fp32 on the host."""
+    with torch.no_grad():
+        return fn(*[t.to(DEV).double() for t in tensors]).float().cpu()
+
+
+@pytest.mark.parametrize("n,k,epilogue", [(768, 256, "rotary"), (512, 256, "plain"), (512, 512, "concat"),
+                                          (256, 512, "residual"), (256, 256, "alpha")])
+@pytest.mark.parametrize("m", [65536, 65536 - 37])
+def test_linear_natural_dispatch_batch32_shapes(m, n, k, epilogue):
+    """The GEMMs of a 32-pair LightGlue layer at their real size (M = 32 * 2 * 1024 rows; also a ragged M): no
+    knob, so launch_gemm picks gemm_nt_kernel<2,2,16> itself (tiles(128,128) >= 768) -- the variant bench.py
+    times.  Every epilogue the layer uses, against float64."""
+    g = gen(m + n + k)
+    w = torch.randn((n, k), generator=g) / k ** 0.5
+    b = torch.randn((n,), generator=g) * 0.3
+    if epilogue == "concat":
+        a0, a1 = torch.randn((m, k // 2), generator=g), torch.randn((m, k // 2), generator=g)
+        out = run_linear(a0, w, b, a1=a1)
+        ref = _ref64(lambda x, y, ww, bb: F.linear(torch.cat([x, y], 1), ww, bb), a0, a1, w, b)
+    else:
+        a = torch.randn((m, k), generator=g)
+        if epilogue == "rotary":
+            ang = torch.randn((m, 32), generator=g) * 2
+            cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+            out = run_linear(a, w, b, cos=cos, sin=sin, rot_cols=512)
+
+            def rot(x, ww, bb, c, s_):
+                y = F.linear(x, ww, bb)
+                t = y[:, :512].reshape(m, 8, 32, 2)
+                r = torch.stack([-t[..., 1], t[..., 0]], -1).reshape(m, 8, 64)
+                qk = y[:, :512].reshape(m, 8, 64) * c[:, None] + r * s_[:, None]
+                return torch.cat([qk.reshape(m, 512), y[:, 512:]], 1)
+            ref = _ref64(rot, a, w, b, cos, sin)
+        elif epilogue == "residual":
+            res = torch.randn((m, n), generator=g)
+            out = run_linear(a, w, b, residual=res)
+            ref = _ref64(lambda x, ww, bb, r: r + F.linear(x, ww, bb), a, w, b, res)
+        elif epilogue == "alpha":
+            out = run_linear(a, w, b, alpha=0.25)
+            ref = _ref64(lambda x, ww, bb: F.linear(x, ww, bb) * 0.25, a, w, b)
+        else:
+            out = run_linear(a, w, b)
+            ref = _ref64(lambda x, ww, bb: F.linear(x, ww, bb), a, w, b)
+    assert maxerr(out, ref) < 2e-5
+
+
+def test_attention_natural_dispatch_64_problems():
+    """64 problems of 1024 x 1024 (the self attention of a 32-pair batch): gfc_attention picks attention_kernel<2,4>
+    itself (wgs(256) >= 1024).  Against a float64 soft-max attention, every problem, every head."""
+    lib = nat.lib()
+    g = gen(64)
+    nprob, n = 64, 1024
+    rows = nprob * n
+    qkv = torch.randn((rows, 768), generator=g)
+    qkv[:, :512] *= 1.5
+    probs = torch.tensor([[i * n, n, i * n, n] for i in range(nprob)], dtype=torch.int32)
+    qd = D(qkv)
+    o = torch.full((rows, 256), float("nan"), device=DEV)
+    nat.check(lib.gfc_attention(nat.ptr(qd), 768, nat.c_void_p(qd.data_ptr() + 256 * 4), 768,
+                                nat.c_void_p(qd.data_ptr() + 512 * 4), 768, nat.ptr(o), 256, nat.ptr(D(probs)), nprob, n,
+                                4, 0.125, None, 0, st()), "attention")
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        x = qd.double().view(nprob, n, 3, 4, 64).permute(2, 0, 3, 1, 4)  # [3, P, H, n, 64]
+        ref = (torch.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, -1) @ x[2]).permute(0, 2, 1, 3).reshape(rows, 256)
+    assert (o.double() - ref).abs().max().item() < 2e-5
 
 
 # ----------------------------------------------------------------------------- attention

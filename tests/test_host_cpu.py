@@ -251,3 +251,22 @@ def test_bench_multiprocess_plumbing_rehearsal():
     assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["pairs_gathered"] == 8 and out["matches_per_rank"] == [10, 11]
+
+
+def test_bench_spawns_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` as a plain command (the form the driver uses): the parent starts the two rank
+    processes itself (free port on 127.0.0.1, RANK / LOCAL_RANK / WORLD_SIZE set), relays exactly one JSON line on
+    stdout and exits with the ranks' status.  A failing rank makes the parent fail."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs",
+           "4", "--rehearse-cpu"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert r.returncode == 0 and len(lines) == 1 and lines[0].startswith("{"), r.stdout + r.stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["pairs_gathered"] == 8 and out["matches_per_rank"] == [10, 11]
+    # mismatch between --gpus and an inherited WORLD_SIZE is an error, not a silent single-rank run
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0
