@@ -9,6 +9,10 @@ int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* hea
 int gfc_rowdot256(const float* x, int ld, int rows, const float* w, const float* bias, float* z, hipStream_t st);
 int gfc_assign_inplace(float* scores, const float* z0, const float* z1, int B, int M, int N, float* stats,
                        hipStream_t st);
+size_t gfc_assign_tail_bytes(int B, int M, int N);
+int gfc_assign_filter_fused(float* scores, const float* z0, const float* z1, int B, int M, int N, float threshold,
+                            int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* stats, void* tail,
+                            hipStream_t st);
 
 extern "C" const char* gfc_version(void) { return "gfc_amd 0.1.0 (gfx950, fp32 MFMA)"; }
 
@@ -307,7 +311,8 @@ extern "C" int gfc_lg_rowdot(const float* x, int ld, int rows, const float* w, c
 extern "C" size_t gfc_lg_assign_workspace_bytes(int B, int M, int N) {
   if (B <= 0 || M <= 0 || N <= 0) return 0;
   const size_t R = (size_t)B * (M + N);
-  return gfc_align(R * 256 * 4) + gfc_align(R * 4) + gfc_align(2 * R * 4) + gfc_align(R * 8);
+  return gfc_align(R * 256 * 4) + gfc_align(R * 4) + gfc_align(2 * R * 4) + gfc_align(R * 8) +
+         gfc_assign_tail_bytes(B, M, N);
 }
 
 // MatchAssignment of layer l + filter_matches (lightglue.py:279-288,294-319).  x0 [B*M,256], x1 [B*N,256].
@@ -326,6 +331,7 @@ extern "C" int gfc_lg_assign(const gfc_lg_params* p, int l, const float* x0, con
   float* z = (float*)(base + gfc_align(R * 256 * 4));
   float* stats = (float*)((char*)z + gfc_align(R * 4));
   void* filt = (char*)stats + gfc_align(2 * R * 4);
+  void* tail = (char*)filt + gfc_align(R * 8);
   float* md1 = md + (size_t)R0 * D;
   GFC_TRY(gfc_linear(x0, D, D, nullptr, 0, 0, p->final_proj_w[l], D, p->final_proj_b[l], nullptr, nullptr, 0.25f,
                      nullptr, nullptr, nullptr, 0, md, D, R0, D, st));
@@ -335,6 +341,8 @@ extern "C" int gfc_lg_assign(const gfc_lg_params* p, int l, const float* x0, con
   GFC_TRY(gfc_rowdot256(x1, D, R1, p->matchability_w[l], p->matchability_b[l], z + R0, st));
   GFC_TRY(gfc_batched_nt(md, D, (long long)M * D, md1, D, (long long)N * D, log_assignment, N + 1,
                          (long long)(M + 1) * (N + 1), M, N, D, B, st));
+  if (gfc_knobs().assign_mode != 1)  // default: statistics in one sweep, final scores + arg-max in a second one
+    return gfc_assign_filter_fused(log_assignment, z, z + R0, B, M, N, threshold, m0, m1, ms0, ms1, stats, tail, st);
   GFC_TRY(gfc_assign_inplace(log_assignment, z, z + R0, B, M, N, stats, st));
   GFC_TRY(gfc_lg_filter_matches(log_assignment, B, M, N, threshold, m0, m1, ms0, ms1, filt, (size_t)B * (M + N) * 8,
                                 st));

@@ -195,8 +195,251 @@ __global__ __launch_bounds__(256) void assign_finalize_kernel(const float* __res
   *o = v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-pass tail of the assignment head (lightglue.py:257-269 + the arg-max half of :294-319): the
+// [B,M,N] similarity block is read ONCE for the row and column soft-max statistics and once more for the final
+// scores, which are written in place together with the row / column arg-max of the finished matrix.
+// HBM traffic: 1 read + (1 read + 1 write) of the matrix; the five-pass form above (kept for
+// gfc_lg_log_assignment / gfc_nn_match and behind GFC_ASSIGN_MODE=1) moved ~8.4x the matrix
+// (profiles/r01_pmc_summary.json: strided column walks read it twice each).
+//
+// Workgroup = one band of AS_RB rows of one pair, 4 waves; a wave walks whole rows with its lanes along the
+// columns (column j = c0 + lane + 64 q, q < AS_NC: contiguous 256-byte segments per load), so
+//   * row statistics are lane-local + one wave reduction per row,
+//   * column statistics live in registers (AS_NC running values per lane) across the rows of the wave, are merged
+//     over the 4 waves in LDS and leave the workgroup as one partial per (band, column); a tiny kernel merges the
+//     bands.  Columns beyond AS_NC*64 are handled in further chunks (row state carried in LDS).
+// Tie breaking as torch.max on CPU: the lowest index among equal maxima.
+// ------------------------------------------------------------------------------------------
+__global__ void mutual_kernel(const float* __restrict__ max0, const int* __restrict__ i0, const int* __restrict__ i1,
+                              int M, int N, float th, long long* __restrict__ m0, long long* __restrict__ m1,
+                              float* __restrict__ ms0, float* __restrict__ ms1);
+#define AS_RB 64  // rows per band (16 per wave)
+#define AS_NC 16  // columns per lane per chunk (1024-column chunks)
+
+__global__ __launch_bounds__(256) void assign_stats_kernel(const float* __restrict__ sim, long long stride_b, int ld,
+                                                           int M, int N, float* __restrict__ rmax,
+                                                           float* __restrict__ rlog, float* __restrict__ cpart) {
+  __shared__ float cm[4][AS_NC * 64], cs[4][AS_NC * 64];
+  __shared__ float row_m[AS_RB], row_s[AS_RB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int band = blockIdx.x, nbands = gridDim.x, b = blockIdx.y;
+  const float* p = sim + b * stride_b;
+  const int i0 = band * AS_RB;
+  for (int c0 = 0; c0 < N; c0 += AS_NC * 64) {
+    float m[AS_NC], sacc[AS_NC];
+#pragma unroll
+    for (int q = 0; q < AS_NC; ++q) { m[q] = -INFINITY; sacc[q] = 0.f; }
+    for (int r = wave; r < AS_RB; r += 4) {  // wave-uniform
+      const int i = i0 + r;
+      if (i >= M) break;
+      const float* row = p + (size_t)i * ld + c0 + lane;
+      float v[AS_NC];
+      float lm = -INFINITY;
+#pragma unroll
+      for (int q = 0; q < AS_NC; ++q) {
+        v[q] = (c0 + lane + 64 * q < N) ? row[64 * q] : -INFINITY;
+        lm = fmaxf(lm, v[q]);
+      }
+      const float old_m = c0 ? row_m[r] : -INFINITY;
+      const float rm = fmaxf(wave_max(lm), old_m);
+      float ls = 0.f;
+#pragma unroll
+      for (int q = 0; q < AS_NC; ++q) ls += (c0 + lane + 64 * q < N) ? expf(v[q] - rm) : 0.f;
+      ls = wave_sum(ls);
+      if (c0) ls += row_s[r] * expf(old_m - rm);
+      if (lane == 0) { row_m[r] = rm; row_s[r] = ls; }
+      // column statistics: online (max, sum of exp) per owned column
+#pragma unroll
+      for (int q = 0; q < AS_NC; ++q) {
+        const float x = v[q];
+        if (x > m[q]) { sacc[q] = sacc[q] * expf(m[q] - x) + 1.f; m[q] = x; } else { sacc[q] += expf(x - m[q]); }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < AS_NC; ++q) { cm[wave][lane + 64 * q] = m[q]; cs[wave][lane + 64 * q] = sacc[q]; }
+    __syncthreads();
+    for (int jj = threadIdx.x; jj < AS_NC * 64; jj += 256) {
+      const int j = c0 + jj;
+      if (j >= N) break;
+      float mm = fmaxf(fmaxf(cm[0][jj], cm[1][jj]), fmaxf(cm[2][jj], cm[3][jj]));
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) t += (cs[w][jj] > 0.f) ? cs[w][jj] * expf(cm[w][jj] - mm) : 0.f;
+      float* o = cpart + (((size_t)b * nbands + band) * N + j) * 2;
+      o[0] = mm; o[1] = t;
+    }
+    __syncthreads();
+  }
+  for (int r = threadIdx.x; r < AS_RB; r += 256) {
+    const int i = i0 + r;
+    if (i < M) { rmax[(size_t)b * M + i] = row_m[r]; rlog[(size_t)b * M + i] = logf(row_s[r]); }
+  }
+}
+
+// merge the band partials of the column statistics: cmax, clog [B][N]
+__global__ void assign_colmerge_kernel(const float* __restrict__ cpart, int nbands, int N, float* __restrict__ cmax,
+                                       float* __restrict__ clog) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= N) return;
+  const float* pp = cpart + ((size_t)b * nbands * N + j) * 2;
+  float mm = -INFINITY;
+  for (int g = 0; g < nbands; ++g) mm = fmaxf(mm, pp[(size_t)g * N * 2]);
+  float t = 0.f;
+  for (int g = 0; g < nbands; ++g) {
+    const float sg = pp[(size_t)g * N * 2 + 1];
+    t += (sg > 0.f) ? sg * expf(pp[(size_t)g * N * 2] - mm) : 0.f;
+  }
+  cmax[(size_t)b * N + j] = mm;
+  clog[(size_t)b * N + j] = logf(t);
+}
+
+// final scores in place (sc = [B][M+1][N+1], the inner block holds sim) + row arg-max (complete) and column arg-max
+// (one partial per band) of the finished inner block
+__global__ __launch_bounds__(256) void assign_finalize_argmax_kernel(
+    float* __restrict__ sc, int M, int N, const float* __restrict__ z0, const float* __restrict__ z1,
+    const float* __restrict__ rmax, const float* __restrict__ rlog, const float* __restrict__ cmax,
+    const float* __restrict__ clog, float* __restrict__ row_best, int* __restrict__ row_arg,
+    float* __restrict__ cpart_v, int* __restrict__ cpart_i) {
+  __shared__ float cv[4][AS_NC * 64];
+  __shared__ int ci[4][AS_NC * 64];
+  __shared__ float row_v[AS_RB];
+  __shared__ int row_i[AS_RB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int band = blockIdx.x, nbands = gridDim.x, b = blockIdx.y;
+  const int ld = N + 1;
+  float* p = sc + (size_t)b * (M + 1) * ld;
+  const int i0 = band * AS_RB;
+  for (int c0 = 0; c0 < N; c0 += AS_NC * 64) {
+    float cmx[AS_NC], clg[AS_NC], lz1[AS_NC], bv[AS_NC];
+    int bi[AS_NC];
+#pragma unroll
+    for (int q = 0; q < AS_NC; ++q) {
+      const int j = c0 + lane + 64 * q;
+      const bool ok = j < N;
+      cmx[q] = ok ? cmax[(size_t)b * N + j] : 0.f;
+      clg[q] = ok ? clog[(size_t)b * N + j] : 0.f;
+      lz1[q] = ok ? logsigmoid(z1[(size_t)b * N + j]) : 0.f;
+      bv[q] = -INFINITY;
+      bi[q] = 0x7FFFFFFF;
+    }
+    for (int r = wave; r < AS_RB; r += 4) {
+      const int i = i0 + r;
+      if (i >= M) break;
+      const float rm = rmax[(size_t)b * M + i], rl = rlog[(size_t)b * M + i];
+      const float zi = z0[(size_t)b * M + i];
+      const float lz0 = logsigmoid(zi);
+      float* row = p + (size_t)i * ld + c0 + lane;
+      float best = -INFINITY;
+      int arg = 0x7FFFFFFF;
+#pragma unroll
+      for (int q = 0; q < AS_NC; ++q) {
+        const int j = c0 + lane + 64 * q;
+        if (j < N) {
+          const float x = row[64 * q];
+          const float s0 = (x - rm) - rl;
+          const float s1 = (x - cmx[q]) - clg[q];
+          const float cert = lz0 + lz1[q];
+          const float v = (s0 + s1) + cert;
+          row[64 * q] = v;
+          if (v > best || arg == 0x7FFFFFFF) { best = v; arg = j; }
+          if (v > bv[q] || bi[q] == 0x7FFFFFFF) { bv[q] = v; bi[q] = i; }
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(arg, o);
+        if (ov > best || (ov == best && oi < arg)) { best = ov; arg = oi; }
+      }
+      if (lane == 0) {
+        if (c0 == 0 || best > row_v[r]) { row_v[r] = best; row_i[r] = arg; }  // earlier chunks hold the lower indices
+        if (c0 + AS_NC * 64 >= N) p[(size_t)i * ld + N] = logsigmoid(-zi);     // dustbin column
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < AS_NC; ++q) { cv[wave][lane + 64 * q] = bv[q]; ci[wave][lane + 64 * q] = bi[q]; }
+    __syncthreads();
+    for (int jj = threadIdx.x; jj < AS_NC * 64; jj += 256) {
+      const int j = c0 + jj;
+      if (j >= N) break;
+      float v = cv[0][jj];
+      int ix = ci[0][jj];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) {
+        const float ov = cv[w][jj];
+        const int oi = ci[w][jj];
+        if (oi != 0x7FFFFFFF && (ix == 0x7FFFFFFF || ov > v || (ov == v && oi < ix))) { v = ov; ix = oi; }
+      }
+      const size_t o = ((size_t)b * nbands + band) * N + j;
+      cpart_v[o] = v;
+      cpart_i[o] = ix;
+      if (band == nbands - 1) p[(size_t)M * ld + j] = logsigmoid(-z1[(size_t)b * N + j]);  // dustbin row
+    }
+    __syncthreads();
+  }
+  for (int r = threadIdx.x; r < AS_RB; r += 256) {
+    const int i = i0 + r;
+    if (i < M) { row_best[(size_t)b * M + i] = row_v[r]; row_arg[(size_t)b * M + i] = row_i[r]; }
+  }
+  if (band == nbands - 1 && threadIdx.x == 0) p[(size_t)M * ld + N] = 0.f;
+}
+
+// column arg-max: merge of the band partials (bands ascend with the row index: strictly greater wins)
+__global__ void assign_colarg_merge_kernel(const float* __restrict__ cpart_v, const int* __restrict__ cpart_i, int nbands,
+                                           int N, int* __restrict__ col_arg) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, b = blockIdx.y;
+  if (j >= N) return;
+  const size_t base = (size_t)b * nbands * N + j;
+  float v = cpart_v[base];
+  int ix = cpart_i[base];
+  for (int g = 1; g < nbands; ++g) {
+    const float ov = cpart_v[base + (size_t)g * N];
+    const int oi = cpart_i[base + (size_t)g * N];
+    if (oi != 0x7FFFFFFF && (ix == 0x7FFFFFFF || ov > v)) { v = ov; ix = oi; }
+  }
+  col_arg[(size_t)b * N + j] = ix;
+}
+
 // In-place variant used by gfc_lg_forward: sim was written by the GEMM straight into the inner block of
 // the [M+1][N+1] output (ld = N+1).
+// scratch of the two-pass tail behind `stats`: column partials of both passes, row / column arg-max
+size_t gfc_assign_tail_bytes(int B, int M, int N) {
+  const size_t nb = (size_t)(M + AS_RB - 1) / AS_RB;
+  return gfc_align((size_t)B * nb * N * 2 * 4) + 2 * gfc_align((size_t)B * nb * N * 4) + gfc_align((size_t)B * M * 8) +
+         gfc_align((size_t)B * N * 4);
+}
+
+// sim (inner block of scores, ld = N+1) -> final scores in place + filter_matches, two sweeps over the matrix.
+// stats: 2*B*(M+N) floats; tail: gfc_assign_tail_bytes().
+int gfc_assign_filter_fused(float* scores, const float* z0, const float* z1, int B, int M, int N, float threshold,
+                            int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* stats, void* tail,
+                            hipStream_t st) {
+  float* rmax = stats;
+  float* rlog = rmax + (size_t)B * M;
+  float* cmax = rlog + (size_t)B * M;
+  float* clog = cmax + (size_t)B * N;
+  const int nb = (M + AS_RB - 1) / AS_RB;
+  char* t = (char*)tail;
+  float* cpart = (float*)t;                t += gfc_align((size_t)B * nb * N * 2 * 4);
+  float* cpv = (float*)t;                  t += gfc_align((size_t)B * nb * N * 4);
+  int* cpi = (int*)t;                      t += gfc_align((size_t)B * nb * N * 4);
+  float* rbest = (float*)t;
+  int* rarg = (int*)(rbest + (size_t)B * M); t += gfc_align((size_t)B * M * 8);
+  int* carg = (int*)t;
+  const long long sb = (long long)(M + 1) * (N + 1);
+  hipLaunchKernelGGL(assign_stats_kernel, dim3(nb, B), dim3(256), 0, st, scores, sb, N + 1, M, N, rmax, rlog, cpart);
+  hipLaunchKernelGGL(assign_colmerge_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, cpart, nb, N, cmax, clog);
+  hipLaunchKernelGGL(assign_finalize_argmax_kernel, dim3(nb, B), dim3(256), 0, st, scores, M, N, z0, z1, rmax, rlog,
+                     cmax, clog, rbest, rarg, cpv, cpi);
+  hipLaunchKernelGGL(assign_colarg_merge_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, cpv, cpi, nb, N, carg);
+  const int mn = M > N ? M : N;
+  hipLaunchKernelGGL(mutual_kernel, dim3((mn + 255) / 256, B), dim3(256), 0, st, rbest, rarg, carg, M, N, threshold,
+                     (long long*)m0, (long long*)m1, ms0, ms1);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
 int gfc_assign_inplace(float* scores, const float* z0, const float* z1, int B, int M, int N, float* stats,
                        hipStream_t st) {
   float* rmax = stats;

@@ -434,7 +434,8 @@ def test_lightglue_without_image_size(golden):
         pred = m({**{k: v for k, v in d.items() if not k.startswith("view")}, **views})
         assert torch.equal(pred["matches0"].cpu(), ref["matches0"]) and torch.equal(pred["matches1"].cpu(), ref["matches1"])
         assert maxerr(pred["matching_scores0"], ref["matching_scores0"]) < TOL
-    assert not torch.equal(ref["matches0"], g["b2_matches0"])  # and it is a different normalisation
+    # and it is a different normalisation than the one with image sizes
+    assert (ref["log_assignment"] - g["b2_log_assignment"]).abs().max() > 1e-3
 
 
 def test_lightglue_empty_set():

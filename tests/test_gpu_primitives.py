@@ -828,3 +828,61 @@ def test_posenc(golden):
     enc = gd["enc0"]  # [2,B,1,N,64]
     assert maxerr(cos.view(b, n, 64), enc[0, :, 0]) < 1e-5
     assert maxerr(sin.view(b, n, 64), enc[1, :, 0]) < 1e-5
+
+
+@pytest.mark.parametrize("b,m,n", [(2, 1024, 1024), (1, 1500, 2100), (3, 130, 67), (1, 1, 5), (2, 64, 1025)])
+def test_assignment_head_two_pass_tail_vs_oracle(b, m, n):
+    """gfc_lg_assign = final_proj + matchability + sim GEMM + the two-pass tail (row / column statistics in one sweep;
+    final scores, dustbin row / column and both arg-maxes in the second) + mutual check, against the oracle's
+    match_assignment + filter_matches (lightglue.py:257-319): log-assignment within 1e-4 relative, matches bit-exact.
+    Ragged sizes: several 1024-column chunks, partial bands, N+1 row pitch that is not a multiple of 4."""
+    import ctypes
+
+    lib = nat.lib()
+    g = gen(b * 1000 + m + n)
+    x0 = torch.randn((b, m, 256), generator=g)
+    x1 = torch.randn((b, n, 256), generator=g)
+    x1[:, : min(m, n)] += 2.5 * x0[:, : min(m, n)].flip(1)  # structure: peaky rows / columns, many mutual matches
+    sd = {"log_assignment.0.final_proj.weight": torch.randn((256, 256), generator=g) / 8,
+          "log_assignment.0.final_proj.bias": torch.randn((256,), generator=g) * 0.1,
+          "log_assignment.0.matchability.weight": torch.randn((1, 256), generator=g) / 16,
+          "log_assignment.0.matchability.bias": torch.randn((1,), generator=g)}
+    ref = olg.match_assignment(sd, "log_assignment.0", x0, x1)
+    r0, r1, rs0, rs1 = olg.filter_matches(ref, 0.1)
+    p = nat.LgParams()
+    p.n_layers = 1
+    p.input_dim = 256
+    p.final_proj_w[0] = D(sd["log_assignment.0.final_proj.weight"]).data_ptr()
+    p.final_proj_b[0] = D(sd["log_assignment.0.final_proj.bias"]).data_ptr()
+    p.matchability_w[0] = D(sd["log_assignment.0.matchability.weight"].reshape(-1)).data_ptr()
+    p.matchability_b[0] = D(sd["log_assignment.0.matchability.bias"]).data_ptr()
+    m0 = torch.empty((b, m), dtype=torch.long, device=DEV)
+    m1 = torch.empty((b, n), dtype=torch.long, device=DEV)
+    s0, s1 = torch.empty((b, m), device=DEV), torch.empty((b, n), device=DEV)
+    la = torch.full((b, m + 1, n + 1), float("nan"), device=DEV)
+    ws = torch.full((lib.gfc_lg_assign_workspace_bytes(b, m, n),), 0xFF, dtype=torch.uint8, device=DEV)
+    x0d, x1d = D(x0.reshape(b * m, 256)), D(x1.reshape(b * n, 256))
+    nat.check(lib.gfc_lg_assign(ctypes.byref(p), 0, nat.ptr(x0d), nat.ptr(x1d), b, m, n, 0.1, nat.ptr(m0), nat.ptr(m1),
+                                nat.ptr(s0), nat.ptr(s1), nat.ptr(la), nat.ptr(ws), ws.numel(), st()), "gfc_lg_assign")
+    torch.cuda.synchronize()
+    err = ((la.cpu() - ref).abs() / (1 + ref.abs())).max().item()
+    assert err < 1e-4, err
+    assert torch.equal(m0.cpu(), r0) and torch.equal(m1.cpu(), r1)
+    assert maxerr(s0, rs0) < 1e-5 and maxerr(s1, rs1) < 1e-5
+    if min(m, n) > 60:
+        assert int((r0 >= 0).sum()) > 0.3 * min(m, n) * b  # the case is not degenerate
+    # stage-isolated: the arg-maxes the fused pass produced equal the standalone filter on the SAME finished matrix
+    f0, f1, _, _ = run_filter(la, 0.1)
+    assert torch.equal(m0.cpu(), f0) and torch.equal(m1.cpu(), f1)
+
+
+def test_assignment_tail_variants_via_knob():
+    """GFC_ASSIGN_MODE=1 (the five-pass tail of round 1) stays selectable and passes the same test."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GFC_ASSIGN_MODE="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "assignment_head_two_pass", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
