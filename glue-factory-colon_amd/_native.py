@@ -65,6 +65,8 @@ SIGNATURES = {
     "gfc_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                               c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "gfc_attention_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_linear_layernorm_gelu": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gfc_layernorm_gelu": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfc_sp_workspace_bytes": (c_size_t, [c_int] * 4),
     "gfc_sp_dense": (c_int, [POINTER(SpParams), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -252,6 +252,15 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
     return gfc_linear(a0, lda0, k0, a1, lda1, k1, w, ldw, bias, nullptr, nullptr, 1.f, resid, rc, rs, rot_cols, y, ldy, R,
                       n, st);
   };
+  // ffn[0] -> LayerNorm -> GELU (lightglue.py:143-148) into hbuf: one row-owning kernel once there are enough
+  // 128-row tiles to cover the chip (>= 128: batch >= 8 pairs of 1024 points), else GEMM + in-place LayerNorm pass
+  const bool ffn_fused = !split && (gfc_knobs().ffn_fused >= 0 ? gfc_knobs().ffn_fused != 0 : R >= 128 * 128);  // knob: 0 off, 1 / 2 tile variants
+  auto ffn01 = [&](const float* a1, const float* w0, const void* w0_split, const float* b0, const float* ln_g,
+                   const float* ln_b) -> int {
+    if (ffn_fused) return gfc_linear_layernorm_gelu(x, D, D, a1, D, D, w0, 512, b0, ln_g, ln_b, hbuf, 512, R, 512, st);
+    GFC_TRY(lin(x, D, D, a1, D, D, w0, w0_split, 512, b0, nullptr, nullptr, nullptr, 0, hbuf, 512, 512));
+    return gfc_layernorm_gelu(hbuf, 512, R, 512, ln_g, ln_b, st);
+  };
   {
 
     // ---- self block (lightglue.py:151-164) ----
@@ -266,9 +275,7 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1s = msg;
     }
-    GFC_TRY(lin(x, D, D, a1s, D, D, p->s_ffn0_w[l], p->s_ffn0_split[l], 512, p->s_ffn0_b[l], nullptr, nullptr, nullptr, 0,
-                hbuf, 512, 512));
-    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->s_ln_g[l], p->s_ln_b[l], st));
+    GFC_TRY(ffn01(a1s, p->s_ffn0_w[l], p->s_ffn0_split[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l]));
     GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], p->s_ffn3_split[l], 512, p->s_ffn3_b[l], x, nullptr, nullptr,
                 0, x, D, D));
     // ---- cross block (lightglue.py:193-222) ----
@@ -281,9 +288,7 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1c = msg;
     }
-    GFC_TRY(lin(x, D, D, a1c, D, D, p->c_ffn0_w[l], p->c_ffn0_split[l], 512, p->c_ffn0_b[l], nullptr, nullptr, nullptr, 0,
-                hbuf, 512, 512));
-    GFC_TRY(gfc_layernorm_gelu(hbuf, 512, R, 512, p->c_ln_g[l], p->c_ln_b[l], st));
+    GFC_TRY(ffn01(a1c, p->c_ffn0_w[l], p->c_ffn0_split[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l]));
     GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], p->c_ffn3_split[l], 512, p->c_ffn3_b[l], x, nullptr, nullptr,
                 0, x, D, D));
     }

@@ -276,6 +276,265 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Row-owning GEMM with LayerNorm(512, eps 1e-5) + GELU(erf) in the epilogue: the first two stages of the LightGlue
+// FFN, Linear(512,512) -> LayerNorm -> GELU (lightglue.py:143-148), in ONE kernel.  The workgroup tile is
+// 128 rows x all 512 columns, so the mean / variance of a row never leave the workgroup and the [M,512]
+// pre-activation makes no round trip through HBM (round 1: GEMM store + a separate in-place LayerNorm pass,
+// 18 launches and 18 x 268 MB per 32-pair step).
+//
+// 8 waves: wm = wave>>2 owns 64 rows (2 MFMA tiles), wn = wave&3 owns 128 columns (4 MFMA tiles): 8 accumulator
+// tiles = 128 registers per lane; per 8-deep k group a wave issues 6 ds_read_b128 for 32 MFMAs.  K tile 16,
+// double-buffered LDS: (128 + 512) x 20 floats x 2 = 100 KB -> one workgroup (2 waves per SIMD) per CU.
+// Row statistics: every lane holds 32 row partials (its 4 columns of 32 rows); a 5-step butterfly over the 32
+// lanes of a half-wave (16+8+4+2+1 = 31 exchanges) leaves each lane with the wave-complete sum of ONE row, the
+// four column waves are combined through LDS.  Two passes (mean, then centred squares) as torch's layer_norm.
+// ---------------------------------------------------------------------------------------------------------------
+#define GW_BN 512
+
+// sum over the 32 lanes (same half-wave) of 32 per-lane values: lane l31 returns the total of value index
+// v(l31) = 16*b0 + 8*b1 + 4*b2 + 2*b3 + b4 (b_k = bit k of l31)
+__device__ __forceinline__ float halfwave_transpose_sum32(const float (&x)[32], int l31) {
+  float y16[16], y8[8], y4[4], y2[2];
+  const bool b0 = l31 & 1, b1 = l31 & 2, b2 = l31 & 4, b3 = l31 & 8, b4 = l31 & 16;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float mine = b0 ? x[16 + i] : x[i], theirs = b0 ? x[i] : x[16 + i];
+    y16[i] = mine + __shfl_xor(theirs, 1);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float mine = b1 ? y16[8 + i] : y16[i], theirs = b1 ? y16[i] : y16[8 + i];
+    y8[i] = mine + __shfl_xor(theirs, 2);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float mine = b2 ? y8[4 + i] : y8[i], theirs = b2 ? y8[i] : y8[4 + i];
+    y4[i] = mine + __shfl_xor(theirs, 4);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float mine = b3 ? y4[2 + i] : y4[i], theirs = b3 ? y4[i] : y4[2 + i];
+    y2[i] = mine + __shfl_xor(theirs, 8);
+  }
+  const float mine = b4 ? y2[1] : y2[0], theirs = b4 ? y2[0] : y2[1];
+  return mine + __shfl_xor(theirs, 16);
+}
+
+// WM = row groups of 64 per workgroup:
+//   WM = 2: 128 x 512 tile, 8 waves, K tile 16, 100 KB LDS: one workgroup per CU;
+//   WM = 1:  64 x 512 tile, 4 waves, K tile 8,   54 KB LDS: two workgroups per CU that run out of phase, so the
+//            VALU-heavy epilogue (LayerNorm + erf, ~50 instructions per element) and the store drain of one
+//            overlap the MFMAs of the other.
+template <int WM>
+__global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmArgs g, const float* __restrict__ gamma,
+                                                                           const float* __restrict__ beta) {
+  constexpr int BM = 64 * WM, BK = WM == 2 ? 16 : 8, LD = BK + 4, C4 = BK / 4;
+  constexpr int TILE = (BM + GW_BN) * LD;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int m0 = blockIdx.x * BM;
+  const float* A0 = g.A0;
+  const float* A1 = g.A1;
+  const int ktiles = (g.K0 + g.K1) / BK;
+
+  // staging: thread -> float4 column s_c4 of tile row s_r0 (weights: rows s_r0 + 128 i).  For the 16-deep tile the
+  // rows are permuted inside blocks of 8 so that the ds_write_b128 is conflict-free (see gemm_nt_kernel).
+  const int s_c4 = (tid % C4) * 4;
+  const int q_ = tid / C4;                       // 0..127
+  const int s_r0 = C4 == 4 ? ((q_ & ~7) | ((q_ & 1) << 2) | ((q_ >> 1) & 3)) : q_;
+  const bool stage_a = s_r0 < BM;                // WM = 1: half of the threads carry an A row
+  const size_t ar = (size_t)min(m0 + (stage_a ? s_r0 : 0), g.M - 1);
+  const float* w0p = g.W + (size_t)(s_r0)*g.ldw + s_c4;
+  const float* w1p = w0p + (size_t)128 * g.ldw;
+  const float* w2p = w0p + (size_t)256 * g.ldw;
+  const float* w3p = w0p + (size_t)384 * g.ldw;
+  float4 areg = make_float4(0.f, 0.f, 0.f, 0.f), wreg0, wreg1, wreg2, wreg3;
+#define GW_LOAD(kt)                                                              \
+  do {                                                                           \
+    const int k0_ = (kt) * BK;                                                   \
+    const bool first_ = k0_ < g.K0;                                              \
+    const float* ab_ = (first_ ? A0 : A1) + (first_ ? k0_ : k0_ - g.K0) + s_c4;  \
+    const size_t ld_ = first_ ? g.lda0 : g.lda1;                                 \
+    if (WM == 2 || stage_a) areg = *reinterpret_cast<const float4*>(ab_ + ar * ld_); \
+    wreg0 = *reinterpret_cast<const float4*>(w0p + k0_);                         \
+    wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                         \
+    wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                         \
+    wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                         \
+  } while (0)
+#define GW_STORE(buf_)                                                           \
+  do {                                                                           \
+    float* bs_ = smem + (buf_) * TILE + BM * LD + s_r0 * LD + s_c4;              \
+    if (WM == 2 || stage_a) *reinterpret_cast<float4*>(smem + (buf_) * TILE + s_r0 * LD + s_c4) = areg; \
+    *reinterpret_cast<float4*>(bs_) = wreg0;                                     \
+    *reinterpret_cast<float4*>(bs_ + 128 * LD) = wreg1;                          \
+    *reinterpret_cast<float4*>(bs_ + 256 * LD) = wreg2;                          \
+    *reinterpret_cast<float4*>(bs_ + 384 * LD) = wreg3;                          \
+  } while (0)
+
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+  const int a_off = (wm * 64 + l31) * LD + 4 * h;
+  const int b_off = BM * LD + (wn * 128 + l31) * LD + 4 * h;
+
+  GW_LOAD(0);
+  GW_STORE(0);
+  if (ktiles > 1) GW_LOAD(1);
+  __syncthreads();
+  for (int kt = 0; kt < ktiles; ++kt) {
+    if (kt + 1 < ktiles) {
+      GW_STORE((kt + 1) & 1);
+      if (kt + 2 < ktiles) GW_LOAD(kt + 2);
+    }
+    const float* ap = smem + (kt & 1) * TILE + a_off;
+    const float* bp = smem + (kt & 1) * TILE + b_off;
+#pragma unroll
+    for (int gk = 0; gk < BK / 8; ++gk) {
+      float4 af[2], bf[4];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * LD + 8 * gk);
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const float4*>(bp + nt * 32 * LD + 8 * gk);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
+          acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
+        }
+    }
+    __syncthreads();
+  }
+#undef GW_LOAD
+#undef GW_STORE
+
+  // ---- epilogue: + bias, LayerNorm over the 512 columns of each row, GELU, store ----
+  float* red = smem;          // [4][BM] per-column-wave row partials
+  float* stat = smem + 4 * BM;  // [BM] mean, then [BM] 1/std
+  float bi[4], ga[4], be[4];
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = wn * 128 + nt * 32 + l31;
+    bi[nt] = g.bias ? g.bias[col] : 0.f;
+    ga[nt] = gamma[col];
+    be[nt] = beta[col];
+  }
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mt][nt][r] += bi[nt];
+  // row of value index v = 16 mt + r held by this lane after the butterfly
+  const int vb = ((l31 & 1) << 4) | ((l31 & 2) << 2) | (l31 & 4) | ((l31 & 8) >> 2) | ((l31 & 16) >> 4);
+  const int my_row = wm * 64 + (vb >> 4) * 32 + acc_row(vb & 15, h);
+  float mu[2][16];
+  {
+    float x[32];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        x[mt * 16 + r] = (acc[mt][0][r] + acc[mt][1][r]) + (acc[mt][2][r] + acc[mt][3][r]);
+    red[wn * BM + my_row] = halfwave_transpose_sum32(x, l31);
+  }
+  __syncthreads();
+  if (tid < BM) stat[tid] = ((red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid])) * (1.f / 512.f);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 m4 = *reinterpret_cast<const float4*>(stat + wm * 64 + mt * 32 + 8 * gq + 4 * h);
+      mu[mt][4 * gq] = m4.x; mu[mt][4 * gq + 1] = m4.y; mu[mt][4 * gq + 2] = m4.z; mu[mt][4 * gq + 3] = m4.w;
+    }
+  {
+    float x[32];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d0 = acc[mt][0][r] - mu[mt][r], d1 = acc[mt][1][r] - mu[mt][r];
+        const float d2 = acc[mt][2][r] - mu[mt][r], d3 = acc[mt][3][r] - mu[mt][r];
+        x[mt * 16 + r] = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
+    red[wn * BM + my_row] = halfwave_transpose_sum32(x, l31);  // `red` was last read before the previous barrier
+  }
+  __syncthreads();
+  if (tid < BM) {
+    const float var = ((red[tid] + red[BM + tid]) + (red[2 * BM + tid] + red[3 * BM + tid])) * (1.f / 512.f);
+    stat[BM + tid] = 1.f / sqrtf(var + 1e-5f);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 r4 = *reinterpret_cast<const float4*>(stat + BM + wm * 64 + mt * 32 + 8 * gq + 4 * h);
+      const float rs[4] = {r4.x, r4.y, r4.z, r4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int r = 4 * gq + j;
+        const int row = m0 + wm * 64 + mt * 32 + acc_row(r, h);
+        if (row < g.M) {
+          float* yp = g.Y + (size_t)row * g.ldy + wn * 128 + l31;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            float y = (acc[mt][nt][r] - mu[mt][r]) * rs[j] * ga[nt] + be[nt];
+#if !defined(GW_DIAG) || GW_DIAG < 1  // diagnostic builds (tools/ab_build.sh): 1 = no erf, 2 = no store either
+            y = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+#endif
+#if !defined(GW_DIAG) || GW_DIAG < 2
+            yp[nt * 32] = y;
+#else
+            if (y == 1234.5678f) yp[nt * 32] = y;
+#endif
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WM>
+static int launch_rows512(const GemmArgs& g, const float* gamma, const float* beta, hipStream_t st) {
+  constexpr int BM = 64 * WM, BK = WM == 2 ? 16 : 8;
+  constexpr size_t lds = (size_t)2 * (BM + GW_BN) * (BK + 4) * sizeof(float);
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_rows512_ln_gelu_kernel<WM>, lds, lds_ok);
+  hipLaunchKernelGGL(gemm_rows512_ln_gelu_kernel<WM>, dim3((g.M + BM - 1) / BM), dim3(256 * WM), lds, st, g, gamma, beta);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+extern "C" int gfc_linear_layernorm_gelu(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1,
+                                         const float* W, int ldw, const float* bias, const float* gamma,
+                                         const float* beta, float* Y, int ldy, int M, int N, void* stream) {
+  if (!A0 || !W || !gamma || !beta || !Y || M <= 0 || K0 <= 0 || K0 % GBK || K1 % GBK || K1 < 0) return GFC_ERR_INVALID;
+  if ((K1 > 0) != (A1 != nullptr)) return GFC_ERR_INVALID;
+  if (lda0 % 4 || (A1 && lda1 % 4) || ldw % 4 || ldy < N) return GFC_ERR_INVALID;
+  if (N != GW_BN) return GFC_ERR_UNSUPPORTED;  // the row statistics span exactly one workgroup tile
+  GemmArgs g = {};
+  g.A0 = A0; g.A1 = A1; g.W = W; g.bias = bias; g.Y = Y;
+  g.lda0 = lda0; g.lda1 = lda1; g.ldw = ldw; g.ldy = ldy;
+  g.K0 = K0; g.K1 = K1; g.M = M; g.N = N; g.alpha = 1.f;
+  // 128-row / 8-wave tiles by default (same-box A/B at M = 65536: 336 us; 64-row tiles with two workgroups per CU
+  // 357 us -- the 8-deep K tile doubles the barriers; GEMM + LayerNorm pass 390 us).  GFC_FFN_FUSED = 1 forces the
+  // 64-row variant.
+  if (gfc_knobs().ffn_fused == 1) return launch_rows512<1>(g, gamma, beta, (hipStream_t)stream);
+  return launch_rows512<2>(g, gamma, beta, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant (128x128 tile, 16-deep K tile, 4 waves): operands go global -> LDS with global_load_lds_dwordx4,
 // no staging registers and no ds_write.  One wave-instruction writes 1 KB = 16 unpadded rows of 16 floats, lane i
 // to byte 16*i; bank conflicts of the fragment reads are avoided by an XOR swizzle of the four 16-byte chunks of a

@@ -106,6 +106,14 @@ size_t gfc_attention_workspace_bytes(int n_problems, int max_nq, int heads);
 int gfc_layernorm_gelu(float* x, int ld, int rows, int width, const float* gamma, const float* beta,
                        void* stream);
 
+/* The first two stages of the LightGlue FFN in one kernel (lightglue.py:143-148, called at :164,221-222):
+ *   Y[M,512] = GELU_erf( LayerNorm_512( [A0 | A1] * W[512,K0+K1]^T + bias ; gamma, beta, eps 1e-5 ) ).
+ * Row-owning workgroup tiles (128 rows x all 512 columns): the row statistics stay on chip and the
+ * pre-activation never reaches HBM.  N must be 512; same operand conventions as gfc_linear. */
+int gfc_linear_layernorm_gelu(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W,
+                              int ldw, const float* bias, const float* gamma, const float* beta, float* Y, int ldy,
+                              int M, int N, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * SuperPoint extractor
  * ---------------------------------------------------------------------------------- */

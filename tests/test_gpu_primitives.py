@@ -487,6 +487,44 @@ def test_linear_natural_dispatch_batch32_shapes(m, n, k, epilogue):
     assert maxerr(out, ref) < 2e-5
 
 
+@pytest.mark.parametrize("m", [65536, 16384 + 77, 100])
+def test_linear_layernorm_gelu_fused(m):
+    """gfc_linear_layernorm_gelu (row-owning 128 x 512 tiles: ffn[0] -> LayerNorm -> GELU of lightglue.py:143-148 in one
+    kernel, two-source A) against float64 torch: F.linear -> layer_norm(eps 1e-5) -> gelu(erf)."""
+    lib = nat.lib()
+    g = gen(m)
+    x, msg = torch.randn((m, 256), generator=g), torch.randn((m, 256), generator=g) * 2 + 0.3
+    w = torch.randn((512, 512), generator=g) / 512 ** 0.5
+    b = torch.randn((512,), generator=g)
+    gamma, beta = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g) * 0.2
+    y = torch.full((m, 512), float("nan"), device=DEV)
+    nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(D(x)), 256, 256, nat.ptr(D(msg)), 256, 256, nat.ptr(D(w)), 512,
+                                            nat.ptr(D(b)), nat.ptr(D(gamma)), nat.ptr(D(beta)), nat.ptr(y), 512, m, 512,
+                                            st()), "linear_ln_gelu")
+    torch.cuda.synchronize()
+    ref = _ref64(lambda a, c, ww, bb, ga, be: F.gelu(F.layer_norm(F.linear(torch.cat([a, c], 1), ww, bb), (512,), ga, be,
+                                                                     1e-5)), x, msg, w, b, gamma, beta)
+    assert maxerr(y, ref) < 2e-5
+    # the unfused pair of kernels agrees to rounding
+    h = run_linear(x, w, b, a1=msg).to(DEV)
+    nat.check(lib.gfc_layernorm_gelu(nat.ptr(h), 512, m, 512, nat.ptr(D(gamma)), nat.ptr(D(beta)), st()), "ln")
+    assert maxerr(y, h) < 1e-5
+    assert lib.gfc_linear_layernorm_gelu(nat.ptr(D(x)), 256, 256, None, 0, 0, nat.ptr(D(w)), 512, nat.ptr(D(b)),
+                                         nat.ptr(D(gamma)), nat.ptr(D(beta)), nat.ptr(y), 256, m, 256, st()) == 3
+
+
+def test_ffn_fused_variants_via_knob():
+    """GFC_FFN_FUSED=1 (64-row tiles, two workgroups per CU) passes the same test as the default 128-row tile."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GFC_FFN_FUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "linear_layernorm_gelu_fused", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
+
+
 def test_attention_natural_dispatch_64_problems():
     """64 problems of 1024 x 1024 (the self attention of a 32-pair batch): gfc_attention picks attention_kernel<2,4>
     itself (wgs(256) >= 1024).  Against a float64 soft-max attention, every problem, every head."""

@@ -64,6 +64,29 @@ def bench_gemm():
         report(f"gemm[{os.environ.get('GFC_GEMM_TILE', 'auto')}] {name}", timeit(fn), 2.0 * R * n * (k0 + k1))
 
 
+def bench_ffn_fused():
+    """ffn[0] -> LayerNorm -> GELU: GEMM + in-place LayerNorm pass vs the row-owning fused kernel."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    R = 65536
+    x, msg = torch.randn((R, 256), device=DEV), torch.randn((R, 256), device=DEV)
+    w = torch.randn((512, 512), device=DEV) / 22
+    b, ga, be = torch.randn((512,), device=DEV), torch.rand((512,), device=DEV) + 0.5, torch.randn((512,), device=DEV)
+    y = torch.empty((R, 512), device=DEV)
+
+    def two():
+        nat.check(lib.gfc_linear(nat.ptr(x), 256, 256, nat.ptr(msg), 256, 256, nat.ptr(w), 512, nat.ptr(b), None, None, 1.0,
+                                 None, None, None, 0, nat.ptr(y), 512, R, 512, st), "linear")
+        nat.check(lib.gfc_layernorm_gelu(nat.ptr(y), 512, R, 512, nat.ptr(ga), nat.ptr(be), st), "ln")
+
+    def one():
+        nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(x), 256, 256, nat.ptr(msg), 256, 256, nat.ptr(w), 512, nat.ptr(b),
+                                                nat.ptr(ga), nat.ptr(be), nat.ptr(y), 512, R, 512, st), "fused")
+
+    report("ffn0 + layernorm_gelu (2 kernels)", timeit(two), 2.0 * R * 512 * 512)
+    report("ffn0+LN+GELU fused (rows512 kernel)", timeit(one), 2.0 * R * 512 * 512)
+
+
 def bench_attn_split():
     lib = nat.lib()
     st = nat.stream_ptr(DEV)
@@ -263,6 +286,8 @@ if __name__ == "__main__":
     args = ap.parse_args()
     if args.only in ("", "gemm"):
         bench_gemm()
+    if args.only == "ffn":
+        bench_ffn_fused()
     if args.only == "sweep":
         bench_gemm_sweep()
     if args.only == "msweep":
