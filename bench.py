@@ -240,7 +240,7 @@ def main():
                     help="skip the extra `experimental_split_arithmetic` leg (profiling runs: only the default path's kernels)")
     ap.add_argument("--linear-arithmetic", default=None, choices=[None, "fp32", "split"],
                     help="LightGlue GEMMs of the timed path (see --conv-arithmetic)")
-    ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split"],
+    ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split", "winograd"],
                     help="3x3 convolutions of the timed path: fp32 MFMA (default) or the experimental bf16x3-split MFMA "
                          "products at fp32 accuracy; the default run additionally reports the split variant as "
                          "`experimental_split_arithmetic` (N = 1 only)")

@@ -26,7 +26,8 @@ class SpParams(Structure):
                 ("wh", c_void_p), ("bias_h", c_void_p), ("scale_h", c_void_p), ("shift_h", c_void_p),
                 ("wp", c_void_p), ("bias_p", c_void_p), ("scale_p", c_void_p), ("shift_p", c_void_p),
                 ("wd", c_void_p), ("bias_d", c_void_p), ("scale_d", c_void_p), ("shift_d", c_void_p),
-                ("desc_dim", c_int), ("conv_mode", c_int), ("w_split", c_void_p * 8), ("wh_split", c_void_p)]
+                ("desc_dim", c_int), ("conv_mode", c_int), ("w_split", c_void_p * 8), ("wh_split", c_void_p),
+                ("w_wino", c_void_p * 8), ("wh_wino", c_void_p)]
 
 
 class Trace(Structure):
@@ -102,6 +103,9 @@ SIGNATURES = {
                                  c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "gfc_attention_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
                                     c_int, c_int, c_float, c_void_p]),
+    "gfc_pack_conv3x3_wino": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gfc_conv3x3_wino": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "gfc_sp_stem_wino": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_refine_keypoints": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "gfc_sp_mask_scores": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p] * 2),

@@ -53,9 +53,18 @@ class PackedSuperPoint:
         # EXPERIMENTAL opt-in: conv_mode "split" (or GFC_CONV_MODE=split) runs the 3x3 convolutions as bf16x3-split
         # MFMA products at fp32 accuracy (csrc/conv_split.hip); default: fp32 MFMA
         mode = conv_mode if conv_mode is not None else os.environ.get("GFC_CONV_MODE", "fp32")
-        if mode not in ("fp32", "split"):
-            raise ValueError(f"conv_mode {mode!r}: 'fp32' or 'split'")
-        self.params.conv_mode = 1 if mode == "split" else 0
+        if mode not in ("fp32", "split", "winograd"):
+            raise ValueError(f"conv_mode {mode!r}: 'fp32', 'winograd' or 'split'")
+        self.params.conv_mode = {"fp32": 0, "split": 1, "winograd": 2}[mode]
+
+        def pack_wino(w):
+            """Filters transformed for Winograd F(2x2,3x3) (G g G^T in float64, done by the library) in fragment order."""
+            w = w.detach().to(device=device, dtype=torch.float32).contiguous()
+            out = torch.empty((16 * w.shape[0] * w.shape[1],), device=device, dtype=torch.float32)
+            nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(w), nat.ptr(out), w.shape[0], w.shape[1], st),
+                      "gfc_pack_conv3x3_wino")
+            self.keep.extend([w, out])
+            return out
 
         def pack_split(w):
             w = w.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -69,6 +78,8 @@ class PackedSuperPoint:
             self.params.w[i] = pack3x3(w).data_ptr()
             if mode == "split" and i >= 1:
                 self.params.w_split[i] = pack_split(w).data_ptr()
+            if mode == "winograd" and i >= 1:
+                self.params.w_wino[i] = pack_wino(w).data_ptr()
             self.params.bias[i] = dev(b).data_ptr()
             sc, sh = opt(sc), opt(sh)
             self.params.scale[i] = sc.data_ptr() if sc is not None else None
@@ -77,6 +88,8 @@ class PackedSuperPoint:
         wh = pack3x3(torch.cat([head_p[0], head_d[0]], 0))
         if mode == "split":
             self.params.wh_split = pack_split(torch.cat([head_p[0], head_d[0]], 0)).data_ptr()
+        if mode == "winograd":
+            self.params.wh_wino = pack_wino(torch.cat([head_p[0], head_d[0]], 0)).data_ptr()
         bh = dev(torch.cat([head_p[1], head_d[1]], 0))
         self.params.wh, self.params.bias_h = wh.data_ptr(), bh.data_ptr()
         if head_p[2] is not None:

@@ -78,6 +78,9 @@ static int traced_stem(gfc_trace* tr, hipStream_t st, const gfc_sp_params* p, co
   int s = p->conv_mode == 1
               ? gfc_sp_stem_split(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_split[1], p->bias[1],
                                   p->scale[1], p->shift[1], y, B, H, W, st)
+          : p->conv_mode == 2
+              ? gfc_sp_stem_wino(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_wino[1], p->bias[1],
+                                 p->scale[1], p->shift[1], y, B, H, W, st)
               : gfc_sp_stem(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w[1], p->bias[1], p->scale[1],
                             p->shift[1], y, B, H, W, st);
   if (s != GFC_OK) return s;
@@ -93,7 +96,12 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   if (!p || !image || !heatmap || !desc_raw || !ws || B <= 0 || (C != 1 && C != 3) || H < 8 || W < 8)
     return GFC_ERR_INVALID;
   if (p->desc_dim <= 0) return GFC_ERR_INVALID;
-  if (p->conv_mode != 0 && p->conv_mode != 1) return GFC_ERR_INVALID;
+  if (p->conv_mode < 0 || p->conv_mode > 2) return GFC_ERR_INVALID;
+  if (p->conv_mode == 2) {
+    if (!p->wh_wino) return GFC_ERR_INVALID;
+    for (int i = 1; i < 8; ++i)
+      if (!p->w_wino[i]) return GFC_ERR_INVALID;
+  }
   if (p->conv_mode == 1) {
     if (!p->wh_split) return GFC_ERR_INVALID;
     for (int i = 1; i < 8; ++i)
@@ -120,6 +128,9 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
     if (p->conv_mode == 1)
       return gfc_conv3x3_split(in, p->w_split[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1,
                                pool, st);
+    if (p->conv_mode == 2)
+      return gfc_conv3x3_wino(in, p->w_wino[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1,
+                              pool, st);
     return gfc_conv3x3(in, p->w[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1, pool, st);
   };
   // conv2a, conv2b+pool
@@ -134,6 +145,8 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   // merged 3x3 heads: [detector hidden | descriptor hidden]
   if (p->conv_mode == 1)
     GFC_TRY(gfc_conv3x3_split(Bf, p->wh_split, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
+  else if (p->conv_mode == 2)
+    GFC_TRY(gfc_conv3x3_wino(Bf, p->wh_wino, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
   else
     GFC_TRY(gfc_conv3x3(Bf, p->wh, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
   const int rows = B * Hs[4] * Ws[4];

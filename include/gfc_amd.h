@@ -58,6 +58,17 @@ int gfc_conv3x3(const float* x, const float* w_packed, const float* bias, const 
                 const float* shift, float* y, int B, int H, int W, int cin, int cout, int relu,
                 int pool, void* stream);
 
+/* The same layer as gfc_conv3x3 (relu / BN affine / pool epilogue, NHWC) as Winograd F(2x2,3x3) on fp32 MFMA:
+ * 16 instead of 36 multiplications per 2x2 output block, fp32 products and accumulation, filter transform done
+ * once in float64 by gfc_pack_conv3x3_wino (w_packed: 16*cout*cin floats in MFMA-fragment order).
+ * cin % 16 == 0, cout % 64 == 0.  gfc_sp_stem_wino = gfc_sp_stem with conv1b in this form. */
+int gfc_pack_conv3x3_wino(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
+int gfc_conv3x3_wino(const float* x, const float* w_wino, const float* bias, const float* scale, const float* shift,
+                     float* y, int B, int H, int W, int cin, int cout, int relu, int pool, void* stream);
+int gfc_sp_stem_wino(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
+                     const float* w2_wino, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
+                     int W, void* stream);
+
 /* Extractor stem: conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in ONE launch.  The first layer is
  * recomputed per workgroup on the 18x18 halo of its 16x16 tile from a 20x20 image patch in LDS, so its
  * [B,H,W,64] output (the largest activation of the network) never exists in HBM.
@@ -146,6 +157,11 @@ typedef struct {
   int conv_mode;
   const void* w_split[8];
   const void* wh_split;
+  /* conv_mode = 2: Winograd F(2x2,3x3) on the fp32 matrix pipe (gfc_conv3x3_wino / gfc_sp_stem_wino): w_wino[1..7] /
+   * wh_wino are the filters transformed (in float64) and packed by gfc_pack_conv3x3_wino; w[0] (conv1a, cin = 1)
+   * is still used.  Every product and accumulation is fp32; 2.25x fewer multiplications than conv_mode 0. */
+  const float* w_wino[8];
+  const float* wh_wino;
 } gfc_sp_params;
 
 typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;

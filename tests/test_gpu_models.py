@@ -155,6 +155,27 @@ def test_split_conv_arithmetic_passes_the_model_parity_tests():
     assert 0 < d < 1e-5, d
 
 
+def test_winograd_conv_arithmetic_passes_the_model_parity_tests():
+    """`conv_arithmetic: winograd` (3x3 convolutions as Winograd F(2x2,3x3) on fp32 MFMA) is held to the same parity
+    tests as the direct fp32-MFMA convolutions: reference golden vectors of both extractors and the pipeline,
+    full-size oracle comparison, odd / extreme sizes.  Process-wide through GFC_CONV_MODE, hence a child process."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GFC_CONV_MODE="winograd")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p",
+                        "no:cacheprovider", "-k", "superpoint_open or superpoint_official or pipeline_golden or "
+                        "vga_1024 or specular or refinement or large_2048"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
+    img = synthetic.synthetic_images(1, 96, 128, seed=8).to(DEV)
+    a = spo(max_num_keypoints=64, dense_outputs=True, conv_arithmetic="fp32")({"image": img})
+    b = spo(max_num_keypoints=64, dense_outputs=True, conv_arithmetic="winograd")({"image": img})
+    d = (a["dense_descriptors"] - b["dense_descriptors"]).abs().max().item()
+    assert 0 < d < 1e-5, d
+
+
 def test_results_do_not_depend_on_workspace_contents(golden):
     """The scratch buffers are caller-owned and uninitialised: poisoning them (0x00 vs 0xFF bytes = NaNs) before a
     call must not change any output.  (Found a real bug once: the scale / orientation scratch of add_scale_ori

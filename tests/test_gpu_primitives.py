@@ -253,6 +253,89 @@ def test_conv3x3_split_accuracy(cin, cout, h, w, pool):
            fp32_mfma_max_abs_err=outs["fp32"])
 
 
+@pytest.mark.parametrize("cin,cout,h,w,pool,bn", [(64, 64, 32, 48, True, True), (64, 128, 30, 40, False, True),
+                                                   (128, 128, 17, 23, True, False), (128, 512, 15, 20, False, True),
+                                                   (64, 64, 33, 47, True, True), (16, 64, 5, 3, False, False),
+                                                   (128, 128, 60, 80, False, True), (64, 64, 240, 320, True, True)])
+def test_conv3x3_winograd(cin, cout, h, w, pool, bn):
+    """gfc_conv3x3_wino (Winograd F(2x2,3x3), fp32 MFMA, filters transformed in float64 at pack time) against a
+    float64 convolution: the error must be of the order of the direct fp32-MFMA kernel's (both ~1e-6 here)."""
+    lib = nat.lib()
+    g = gen(cin + cout + h + 1)
+    b = 3
+    x = torch.randn((b, cin, h, w), generator=g)
+    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)
+    bias = torch.randn((cout,), generator=g) * 0.1
+    scale = torch.rand((cout,), generator=g) + 0.5 if bn else None
+    shift = torch.randn((cout,), generator=g) * 0.1 if bn else None
+    if bn:
+        scale[::3] *= -1  # negative BN gains: pooling must come after the affine
+    ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1))
+    if bn:
+        ref = ref * scale.double()[None, :, None, None] + shift.double()[None, :, None, None]
+    if pool:
+        ref = F.max_pool2d(ref, 2, 2)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    ho, wo = (h // 2, w // 2) if pool else (h, w)
+    errs = {}
+    for name in ("direct", "winograd"):
+        y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
+        if name == "direct":
+            if cin % 32:
+                continue
+            wp = torch.empty((9, cout, cin), device=DEV)
+            nat.check(lib.gfc_pack_conv3x3(nat.ptr(D(wt)), nat.ptr(wp), cout, cin, st()), "pack")
+            nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(D(bias)), nat.ptr(D(scale)), nat.ptr(D(shift)),
+                                      nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()), "conv")
+        else:
+            ww = torch.empty((16 * cout * cin,), device=DEV)
+            nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(D(wt)), nat.ptr(ww), cout, cin, st()), "pack_wino")
+            nat.check(lib.gfc_conv3x3_wino(nat.ptr(xd), nat.ptr(ww), nat.ptr(D(bias)), nat.ptr(D(scale)),
+                                           nat.ptr(D(shift)), nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()),
+                      "conv_wino")
+        torch.cuda.synchronize()
+        errs[name] = (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
+    assert errs["winograd"] < 2e-5, errs
+    if "direct" in errs:
+        assert errs["winograd"] < 3 * errs["direct"] + 1e-6, errs
+    from parity_utils import record
+    record(f"conv_wino_err_{cin}_{cout}_{h}x{w}_{'pool' if pool else 'nopool'}", winograd_max_abs_err=errs["winograd"],
+           direct_fp32_mfma_max_abs_err=errs.get("direct", -1.0))
+
+
+@pytest.mark.parametrize("h,w,bn", [(48, 64, True), (37, 51, True), (32, 32, False), (480, 640, True)])
+def test_stem_winograd(h, w, bn):
+    """gfc_sp_stem_wino: conv1a (direct, on the halo patch) + conv1b (Winograd) + pool against float64 torch."""
+    lib = nat.lib()
+    g = gen(h * w + 3)
+    b = 2
+    img = torch.rand((b, 1, h, w), generator=g)
+    w1 = torch.randn((64, 1, 3, 3), generator=g) / 3
+    b1 = torch.randn((64,), generator=g) * 0.1
+    w2 = torch.randn((64, 64, 3, 3), generator=g) / 24
+    b2 = torch.randn((64,), generator=g) * 0.1
+    s1 = s2 = t1 = t2 = None
+    ref = F.relu(F.conv2d(img.double(), w1.double(), b1.double(), padding=1))
+    if bn:
+        s1, t1 = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+        s2, t2 = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+        s2[::5] *= -1
+        ref = ref * s1.double()[None, :, None, None] + t1.double()[None, :, None, None]
+    ref = F.relu(F.conv2d(ref, w2.double(), b2.double(), padding=1))
+    if bn:
+        ref = ref * s2.double()[None, :, None, None] + t2.double()[None, :, None, None]
+    ref = F.max_pool2d(ref, 2, 2)
+    w2w = torch.empty((16 * 64 * 64,), device=DEV)
+    nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(D(w2)), nat.ptr(w2w), 64, 64, st()), "pack_wino")
+    w1p = D(w1.reshape(64, 9).t().contiguous())  # [9][64]
+    y = torch.full((b, h // 2, w // 2, 64), float("nan"), device=DEV)
+    nat.check(lib.gfc_sp_stem_wino(nat.ptr(D(img.reshape(b, h, w))), nat.ptr(w1p), nat.ptr(D(b1)), nat.ptr(D(s1)),
+                                   nat.ptr(D(t1)), nat.ptr(w2w), nat.ptr(D(b2)), nat.ptr(D(s2)), nat.ptr(D(t2)),
+                                   nat.ptr(y), b, h, w, st()), "stem_wino")
+    torch.cuda.synchronize()
+    assert (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() < 2e-5
+
+
 def test_conv3x3_rejects_bad_shapes():
     lib = nat.lib()
     x = torch.zeros(16, device=DEV)

@@ -215,6 +215,51 @@ def bench_conv():
         report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
 
 
+def bench_conv_wino():
+    """Winograd F(2x2,3x3) fp32-MFMA convolution at the shapes of bench_conv; TFLOP/s are ALGORITHMIC (direct-
+    convolution FLOPs / time), the matrix pipe executes 4/9 of them."""
+    lib = nat.lib()
+    st = nat.stream_ptr(DEV)
+    B = 32
+    for name, h, w, cin, cout, pool in [("wino conv1b 64->64 @480x640 +pool", 480, 640, 64, 64, 1),
+                                        ("wino conv2a 64->64 @240x320", 240, 320, 64, 64, 0),
+                                        ("wino conv2b 64->64 @240x320 +pool", 240, 320, 64, 64, 1),
+                                        ("wino conv3a 64->128 @120x160", 120, 160, 64, 128, 0),
+                                        ("wino conv3b 128->128 @120x160 +pool", 120, 160, 128, 128, 1),
+                                        ("wino conv4a 128->128 @60x80", 60, 80, 128, 128, 0),
+                                        ("wino heads 128->512 @60x80", 60, 80, 128, 512, 0)]:
+        x = torch.randn((B, h, w, cin), device=DEV)
+        wt = torch.randn((cout, cin, 3, 3), device=DEV) / (3 * cin ** 0.5)
+        ww = torch.empty((16 * cout * cin,), device=DEV)
+        nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(wt), nat.ptr(ww), cout, cin, st), "pack")
+        bias = torch.randn((cout,), device=DEV)
+        sc = torch.rand((cout,), device=DEV) + 0.5
+        sh = torch.randn((cout,), device=DEV)
+        y = torch.empty((B, h // 2 if pool else h, w // 2 if pool else w, cout), device=DEV)
+
+        def fn():
+            nat.check(lib.gfc_conv3x3_wino(nat.ptr(x), nat.ptr(ww), nat.ptr(bias), nat.ptr(sc), nat.ptr(sh), nat.ptr(y),
+                                           B, h, w, cin, cout, 1, pool, st), "conv_wino")
+
+        report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
+    B, h, w = 64, 480, 640
+    img = torch.rand((B, h, w), device=DEV)
+    w1 = torch.randn((9, 64), device=DEV) / 3
+    w2 = torch.randn((64, 64, 3, 3), device=DEV) / 24
+    w2w = torch.empty((16 * 64 * 64,), device=DEV)
+    nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(w2), nat.ptr(w2w), 64, 64, st), "pack")
+    b1, b2 = torch.randn((64,), device=DEV), torch.randn((64,), device=DEV)
+    s1, s2 = torch.rand((64,), device=DEV) + 0.5, torch.rand((64,), device=DEV) + 0.5
+    t1, t2 = torch.randn((64,), device=DEV), torch.randn((64,), device=DEV)
+    y = torch.empty((B, h // 2, w // 2, 64), device=DEV)
+
+    def fn2():
+        nat.check(lib.gfc_sp_stem_wino(nat.ptr(img), nat.ptr(w1), nat.ptr(b1), nat.ptr(s1), nat.ptr(t1), nat.ptr(w2w),
+                                       nat.ptr(b2), nat.ptr(s2), nat.ptr(t2), nat.ptr(y), B, h, w, st), "stem_wino")
+
+    report("wino stem conv1a+conv1b+pool @480x640 x64", timeit(fn2, iters=10), 2.0 * 9 * B * h * w * (64 + 64 * 64))
+
+
 def bench_conv_split():
     """Experimental bf16x3-split convolution at the same shapes as bench_conv (TFLOP/s of fp32-equivalent work)."""
     lib = nat.lib()
@@ -286,6 +331,10 @@ if __name__ == "__main__":
     args = ap.parse_args()
     if args.only in ("", "gemm"):
         bench_gemm()
+    if args.only == "wino":
+        bench_conv_wino()
+        bench_conv()
+        bench_stem()
     if args.only == "ffn":
         bench_ffn_fused()
     if args.only == "sweep":
