@@ -47,11 +47,12 @@ def pmc_traffic_bytes():
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
     command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py).  PMC counters
     cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
     try:
         with open(path) as f:
             summary = json.load(f)
-        key = next(k for k in summary if k.startswith("conv3x3_mfma_kernel<true, true"))  # the stem variant
+        key = next(k for k in summary if k.startswith("void conv3x3_wino_kernel<true, true")
+                   or k.startswith("conv3x3_wino_kernel<true, true"))  # the stem variant of the default path
         return summary[key]["hbm_bytes_per_launch"]  # 64-image launches
     except (OSError, KeyError, ValueError, StopIteration):
         return None
@@ -128,6 +129,20 @@ def torch_eager_same_gpu(dev, n_pairs: int = 16, iters: int = 4):
         dt = time.perf_counter() - t0
     return {"value": round(n_pairs * iters / dt, 2), "unit": "image-pairs/sec",
             "sample": f"{iters} iterations of {n_pairs} VGA pairs, oracle tensors on cuda:0 (PyTorch-ROCm eager fp32)"}
+
+
+def conv_mode_of(arg):
+    """The convolution arithmetic a module built with conf.conv_arithmetic = arg ends up with."""
+    return arg if arg is not None else os.environ.get("GFC_CONV_MODE", "winograd")
+
+
+def stem_kernel_name(arg):
+    mode = conv_mode_of(arg)
+    if mode == "winograd":
+        return "conv3x3_wino_kernel<true, true> (stem: conv1a direct + conv1b Winograd F(2x2,3x3) + ReLU + BN + 2x2 max-pool)"
+    if mode == "split":
+        return "conv3x3_split_kernel (stem, experimental split arithmetic)"
+    return "conv3x3_mfma_kernel<true, true, 16, false> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)"
 
 
 def spawn_ranks(n: int) -> int:
@@ -391,19 +406,30 @@ def main():
                        "pairs_gathered": n_pairs_total, "extractor_calls_per_step": 1 if args.joint_extract else 2, "final_gather_ms": round(gather_ms, 3),
                        "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
                        "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_mfma_kernel<true, true, 16, false> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)",
+            "roofline": {"bound": "mfma", "kernel": stem_kernel_name(args.conv_arithmetic),
                          "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          # the committed PMC passes are of the default command; other shapes: not measured
-                         "traffic": pmc_traffic_bytes() if (args.workload == "c2" and imgs_per_launch == 64) else None,
+                         "traffic": pmc_traffic_bytes() if (args.workload == "c2" and imgs_per_launch == 64
+                                                            and conv_mode_of(args.conv_arithmetic) == "winograd") else None,
                          "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of the "
-                                         "default command (profiles/r01_pmc_summary.json); algorithmic per launch: "
+                                         "default command (profiles/r02_pmc_summary.json); algorithmic per launch: "
                                          f"{imgs_per_launch * H * W * 4 / 1e6:.1f} MB image in + "
                                          f"{imgs_per_launch * (H // 2) * (W // 2) * 64 * 4 / 1e6:.1f} MB pooled "
                                          "activation out",
                          "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),
                          "flops_per_launch": flops_per_launch},
         }
+        if conv_mode_of(args.conv_arithmetic) == "winograd":
+            # `achieved` above is ALGORITHMIC (direct-convolution FLOPs of SURVEY.md 8d / launch time), as the contract
+            # defines it; the Winograd kernel issues 16 instead of 36 multiplications per 2x2 output block and cin, so
+            # the matrix pipe executes 4/9 of conv1b's algorithmic FLOPs (conv1a runs on the VALU).
+            executed = 2 * 4 * 64 * 64 * H * W * imgs_per_launch
+            mfma_tf = executed / (avg_ms * 1e-3) / 1e12 if durs else 0.0
+            out["roofline"]["mfma_executed_tflops"] = round(mfma_tf, 2)
+            out["roofline"]["mfma_frac"] = round(mfma_tf / FP32_MFMA_PEAK_TFLOPS, 4)
+            out["roofline"]["note"] = ("Winograd F(2x2,3x3) on fp32 MFMA: frac = algorithmic FLOPs / peak may exceed 1; "
+                                       "mfma_frac = FLOPs the matrix pipe actually executes / peak")
         if split_info is not None:
             out["experimental_split_arithmetic"] = split_info
         if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":

@@ -50,9 +50,11 @@ class PackedSuperPoint:
         def opt(t):
             return None if t is None else dev(t)
 
-        # EXPERIMENTAL opt-in: conv_mode "split" (or GFC_CONV_MODE=split) runs the 3x3 convolutions as bf16x3-split
-        # MFMA products at fp32 accuracy (csrc/conv_split.hip); default: fp32 MFMA
-        mode = conv_mode if conv_mode is not None else os.environ.get("GFC_CONV_MODE", "fp32")
+        # 3x3 convolutions: "winograd" (default; F(2x2,3x3) on the fp32 matrix pipe, csrc/conv_wino.hip: fp32 products
+        # and accumulation, 2.25x fewer of them), "fp32" (direct implicit GEMM on fp32 MFMA, csrc/conv.hip) or the
+        # EXPERIMENTAL opt-in "split" (bf16x3-split MFMA products, csrc/conv_split.hip).  $GFC_CONV_MODE overrides the
+        # default for modules that do not set conf.conv_arithmetic.
+        mode = conv_mode if conv_mode is not None else os.environ.get("GFC_CONV_MODE", "winograd")
         if mode not in ("fp32", "split", "winograd"):
             raise ValueError(f"conv_mode {mode!r}: 'fp32', 'winograd' or 'split'")
         self.params.conv_mode = {"fp32": 0, "split": 1, "winograd": 2}[mode]

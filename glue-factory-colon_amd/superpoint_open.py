@@ -43,8 +43,9 @@ class SuperPoint(BaseModel):
         "dense_outputs": None,
         "weights": None,  # local path of pretrained weights; "synthetic[:seed]" = name-seeded weights
         "filter_specular_keypoints": True,
-        # MI355X addition: None = fp32 MFMA (or $GFC_CONV_MODE); "split" = experimental bf16x3-split MFMA products at
-        # fp32 accuracy for the 3x3 convolutions (csrc/conv_split.hip), +24 % end to end
+        # MI355X addition, arithmetic of the 3x3 convolutions: None = $GFC_CONV_MODE or "winograd" (Winograd F(2x2,3x3)
+        # on fp32 MFMA: same fp32 products / accumulation, 2.25x fewer of them); "fp32" = direct implicit GEMM on fp32
+        # MFMA; "split" = experimental bf16x3-split MFMA products (csrc/conv_split.hip)
         "conv_arithmetic": None,
     }
     required_data_keys = ["image"]

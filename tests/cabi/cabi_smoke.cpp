@@ -51,6 +51,12 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&dp, w.size() * 4));
     GFC_OK_(gfc_pack_conv3x3(dw, dp, cout[i], cin[i], st));
     p.w[i] = dp; p.bias[i] = upload(b); p.scale[i] = upload(sc); p.shift[i] = upload(sh);
+    if (i >= 1) {  // the default arithmetic of the boundary modules: Winograd F(2x2,3x3) filters, packed by the library
+      float* dq = nullptr;
+      HIP_OK(hipMalloc(&dq, (size_t)16 * cout[i] * cin[i] * 4));
+      GFC_OK_(gfc_pack_conv3x3_wino(dw, dq, cout[i], cin[i], st));
+      p.w_wino[i] = dq;
+    }
   }
   {
     std::vector<float> w = rd((size_t)512 * 128 * 9), b = rd(512), sc = rd(512), sh = rd(512);
@@ -59,6 +65,10 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&dp, w.size() * 4));
     GFC_OK_(gfc_pack_conv3x3(dw, dp, 512, 128, st));
     p.wh = dp; p.bias_h = upload(b); p.scale_h = upload(sc); p.shift_h = upload(sh);
+    float* dq = nullptr;
+    HIP_OK(hipMalloc(&dq, (size_t)16 * 512 * 128 * 4));
+    GFC_OK_(gfc_pack_conv3x3_wino(dw, dq, 512, 128, st));
+    p.wh_wino = dq;
   }
   { auto w = rd(65 * 256), b = rd(65), sc = rd(65), sh = rd(65);
     p.wp = upload(w); p.bias_p = upload(b); p.scale_p = upload(sc); p.shift_p = upload(sh); }
@@ -66,6 +76,7 @@ int main(int argc, char** argv) {
     if (sh.empty()) return 1;
     p.wd = upload(w); p.bias_d = upload(b); p.scale_d = upload(sc); p.shift_d = upload(sh); }
   p.desc_dim = 256;
+  p.conv_mode = 2;  // Winograd on fp32 MFMA, the modules' default (0 = direct implicit GEMM)
   fclose(f);
 
   const int B = 1, h8 = H / 8, w8 = W / 8;

@@ -155,15 +155,16 @@ def test_split_conv_arithmetic_passes_the_model_parity_tests():
     assert 0 < d < 1e-5, d
 
 
-def test_winograd_conv_arithmetic_passes_the_model_parity_tests():
-    """`conv_arithmetic: winograd` (3x3 convolutions as Winograd F(2x2,3x3) on fp32 MFMA) is held to the same parity
-    tests as the direct fp32-MFMA convolutions: reference golden vectors of both extractors and the pipeline,
-    full-size oracle comparison, odd / extreme sizes.  Process-wide through GFC_CONV_MODE, hence a child process."""
+def test_direct_conv_arithmetic_passes_the_model_parity_tests():
+    """The default is `conv_arithmetic: winograd` (3x3 convolutions as Winograd F(2x2,3x3) on fp32 MFMA); the direct
+    implicit-GEMM convolutions (`fp32`) stay selectable and are held to the same parity tests: reference golden
+    vectors of both extractors and the pipeline, full-size oracle comparison, odd / extreme sizes.  Process-wide
+    through GFC_CONV_MODE, hence a child process."""
     import os
     import subprocess
     import sys
 
-    env = dict(os.environ, GFC_CONV_MODE="winograd")
+    env = dict(os.environ, GFC_CONV_MODE="fp32")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p",
                         "no:cacheprovider", "-k", "superpoint_open or superpoint_official or pipeline_golden or "
                         "vga_1024 or specular or refinement or large_2048"],
