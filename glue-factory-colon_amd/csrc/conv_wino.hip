@@ -36,6 +36,9 @@
 #define WPATCH (WP_R * WP_C * WKC)  // floats per patch buffer
 #define WIM_R 20                   // STEM: image patch rows
 #define WIM_C 12                   // STEM: image patch columns
+#ifndef WINO_DIAG
+#define WINO_DIAG 0                // diagnostic builds (tools/ab_build.sh): 1 no conv1a, 2 no B reloads, 4 no epilogue, 8 no patch loads
+#endif
 
 struct WinoArgs {
   const float* x;
@@ -94,31 +97,37 @@ __device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float
 template <bool POOL, bool STEM>
 __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* in_s = smem;                      // [2][WPATCH]; the epilogue exchange buffer (16384 floats) aliases it
-  float* img_s = smem + 2 * WPATCH;        // STEM: [WIM_R][WIM_C] image patch
-  float* c1_s = img_s + WIM_R * WIM_C;     // STEM: conv1a w [9][64], b [64], s [64], t [64]
+  float* in_s = smem;               // [2][WPATCH]; the epilogue exchange buffer (16384 floats) aliases it
+  float* img_s = smem + 16384;      // STEM: [WIM_R][WIM_C] image patch (behind the exchange buffer: it is filled for the
+  float* c1_s = img_s + WIM_R * WIM_C;  //   next item while the epilogue runs); conv1a w [9][64], b [64], s [64], t [64]
 
-  const int tid = threadIdx.x, lane = tid & 63, xi = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int xi = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave index, kept scalar: everything derived from it
+  const int l31 = lane & 31, h = lane >> 5;                 // (filter stream base, transform rows) stays in SGPRs
   const int cin = a.cin, nchunks = cin / WKC;
 
-  // work item: tile + ntiles * (output-channel block)
+  // Persistent workgroups: work item = tile + ntiles * (output-channel block); a workgroup walks the items
+  // blockIdx.x, blockIdx.x + gridDim.x, ...  The first input patch, the first filter fragments (and, in the stem, the
+  // image patch) of the NEXT item are requested during the last chunk of the current one and land under its epilogue.
+  // Exit: the item index is a pure function of blockIdx / gridDim (no queue, no inter-workgroup dependency).
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
-  int t_ = blockIdx.x % ntiles;
-  const int nb = blockIdx.x / ntiles;
-  const int x0 = (t_ % a.tiles_x) * WT_X;
-  t_ /= a.tiles_x;
-  const int y0 = (t_ % a.tiles_y) * WT_Y;
-  const int b = t_ / a.tiles_y;
-  const float* xin = a.x + (size_t)b * a.H * a.W * (STEM ? 1 : cin);
-
-  // ---- B stream: fragments of this wave's four positions, contiguous per k group (8 x 64 float4) ----
-  const float4* wp = reinterpret_cast<const float4*>(a.w) + (((size_t)nb * 4 + xi) * (cin / 8)) * 512 + lane;
-  float4 bq[4][2];
-#pragma unroll
-  for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) bq[nu][nt] = wp[(nu * 2 + nt) * 64];
+  const int nitems = ntiles * (a.cout / 64);
+  int item = blockIdx.x;
+  int x0, y0, b, nb;
+  const float* xin;
+  const float4* wp;  // B stream: fragments of this wave's four positions, contiguous per k group (8 x 64 float4)
+#define WINO_DECODE(w_, x0_, y0_, b_, nb_, xin_, wp_)                                              \
+  do {                                                                                             \
+    int t_ = (w_) % ntiles;                                                                        \
+    nb_ = (w_) / ntiles;                                                                           \
+    x0_ = (t_ % a.tiles_x) * WT_X;                                                                 \
+    t_ /= a.tiles_x;                                                                               \
+    y0_ = (t_ % a.tiles_y) * WT_Y;                                                                 \
+    b_ = t_ / a.tiles_y;                                                                           \
+    xin_ = a.x + (size_t)b_ * a.H * a.W * (STEM ? 1 : cin);                                        \
+    wp_ = reinterpret_cast<const float4*>(a.w) + (((size_t)nb_ * 4 + xi) * (cin / 8)) * 512;        \
+  } while (0)
+  WINO_DECODE(item, x0, y0, b, nb, xin, wp);
 
   // ---- patch staging: 18 x 10 pixels x 4 float4 = 720 float4 per chunk, three per thread ----
   float4 ireg[3];
@@ -129,57 +138,74 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     const int idx = tid + 256 * i;
     const int pix = idx >> 2, c4 = idx & 3;
     const int py = pix / 10, px = pix - py * 10;
-    const int gy = y0 - 1 + py, gx = x0 - 1 + px;
     const int R = (py >> 1) + (py & 1) * 9, C = (px >> 1) + (px & 1) * 5;
     st_off[i] = idx < 720 ? (R * WP_C + C) * WKC + ((c4 ^ (R & 3)) << 2) : -1;
-    const bool inside = idx < 720 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-    if constexpr (STEM) st_gofs[i] = inside ? (py * WIM_C + px) : -1;  // offset into the image patch (tap (0,0) corner)
-    else st_gofs[i] = inside ? (int)(((size_t)gy * a.W + gx) * cin + c4 * 4) : -1;
   }
-#define WINO_LOAD_IN(chunk_)                                                                      \
+#define WINO_GOFS(y0_, x0_)                                                                        \
+  _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                               \
+    const int py_ = ((tid + 256 * i_) >> 2) / 10, px_ = ((tid + 256 * i_) >> 2) - py_ * 10;        \
+    const int gy_ = (y0_) - 1 + py_, gx_ = (x0_) - 1 + px_;                                        \
+    const bool in_ = st_off[i_] >= 0 && gy_ >= 0 && gy_ < a.H && gx_ >= 0 && gx_ < a.W;            \
+    if constexpr (STEM) st_gofs[i_] = in_ ? (py_ * WIM_C + px_) : -1; /* image-patch offset, tap (0,0) */ \
+    else st_gofs[i_] = in_ ? (int)(((size_t)gy_ * a.W + gx_) * cin + ((tid & 3) << 2)) : -1;       \
+  }
+#define WINO_LOAD_IN(xin_, chunk_)                                                                \
   _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                               \
     float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-    if (st_gofs[i_] >= 0) v_ = *reinterpret_cast<const float4*>(xin + st_gofs[i_] + (chunk_) * WKC); \
+    if (st_gofs[i_] >= 0 && !(WINO_DIAG & 8)) v_ = *reinterpret_cast<const float4*>((xin_) + st_gofs[i_] + (chunk_) * WKC); \
     ireg[i_] = v_;                                                                                 \
   }
 #define WINO_FILL_IN(chunk_)                                                                      \
-  _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                               \
-    float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                   \
-    if (st_gofs[i_] >= 0) {                                                                        \
-      const int c0_ = (chunk_) * WKC + (((tid + 256 * i_) & 3) << 2);                              \
-      const float* ip_ = img_s + st_gofs[i_];                                                      \
-      _Pragma("unroll") for (int t2_ = 0; t2_ < 9; ++t2_) {                                        \
-        const float f_ = ip_[(t2_ / 3) * WIM_C + t2_ % 3];                                         \
-        const float4 w_ = *reinterpret_cast<const float4*>(c1_s + t2_ * 64 + c0_);                 \
-        v_.x = fmaf(f_, w_.x, v_.x); v_.y = fmaf(f_, w_.y, v_.y);                                  \
-        v_.z = fmaf(f_, w_.z, v_.z); v_.w = fmaf(f_, w_.w, v_.w);                                  \
+  {                                                                                                \
+    /* STEM: conv1a on this thread's three patch pieces.  The pieces share their channel quad (256 = 0 mod 4):   \
+       the 12 constant quads are read from LDS once per chunk (re-reading them per piece costs 10 % of the       \
+       kernel: the LDS pipe is shared with the fragment reads of all eight resident waves). */                 \
+    const int c0_ = (chunk_) * WKC + ((tid & 3) << 2);                                             \
+    float4 wv_[9];                                                                                 \
+    _Pragma("unroll") for (int t2_ = 0; t2_ < 9; ++t2_)                                            \
+        wv_[t2_] = *reinterpret_cast<const float4*>(c1_s + t2_ * 64 + c0_);                        \
+    const float4 b1_ = *reinterpret_cast<const float4*>(c1_s + 576 + c0_);                         \
+    const float4 s1_ = *reinterpret_cast<const float4*>(c1_s + 640 + c0_);                         \
+    const float4 t1_ = *reinterpret_cast<const float4*>(c1_s + 704 + c0_);                         \
+    _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                             \
+      float4 v_ = make_float4(0.f, 0.f, 0.f, 0.f);  /* outside the image: conv1b's zero padding */ \
+      if (st_gofs[i_] >= 0 && !(WINO_DIAG & 1)) {                                                  \
+        const float* ip_ = img_s + st_gofs[i_];                                                    \
+        _Pragma("unroll") for (int t2_ = 0; t2_ < 9; ++t2_) {                                      \
+          const float f_ = ip_[(t2_ / 3) * WIM_C + t2_ % 3];                                       \
+          v_.x = fmaf(f_, wv_[t2_].x, v_.x); v_.y = fmaf(f_, wv_[t2_].y, v_.y);                    \
+          v_.z = fmaf(f_, wv_[t2_].z, v_.z); v_.w = fmaf(f_, wv_[t2_].w, v_.w);                    \
+        }                                                                                          \
+        v_.x = fmaxf(v_.x + b1_.x, 0.f) * s1_.x + t1_.x; v_.y = fmaxf(v_.y + b1_.y, 0.f) * s1_.y + t1_.y; \
+        v_.z = fmaxf(v_.z + b1_.z, 0.f) * s1_.z + t1_.z; v_.w = fmaxf(v_.w + b1_.w, 0.f) * s1_.w + t1_.w; \
       }                                                                                            \
-      const float4 b1_ = *reinterpret_cast<const float4*>(c1_s + 576 + c0_);                       \
-      const float4 s1_ = *reinterpret_cast<const float4*>(c1_s + 640 + c0_);                       \
-      const float4 t1_ = *reinterpret_cast<const float4*>(c1_s + 704 + c0_);                       \
-      v_.x = fmaxf(v_.x + b1_.x, 0.f) * s1_.x + t1_.x; v_.y = fmaxf(v_.y + b1_.y, 0.f) * s1_.y + t1_.y; \
-      v_.z = fmaxf(v_.z + b1_.z, 0.f) * s1_.z + t1_.z; v_.w = fmaxf(v_.w + b1_.w, 0.f) * s1_.w + t1_.w; \
+      ireg[i_] = v_;                                                                               \
     }                                                                                              \
-    ireg[i_] = v_;                                                                                 \
   }
 #define WINO_STORE_IN(buf_)                                                                       \
   _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_)                                                 \
     if (st_off[i_] >= 0) *reinterpret_cast<float4*>(in_s + (buf_) * WPATCH + st_off[i_]) = ireg[i_];
+#define WINO_IMG(xin_, y0_, x0_)                                                                   \
+  ((tid < WIM_R * WIM_C && (y0_) - 2 + tid / WIM_C >= 0 && (y0_) - 2 + tid / WIM_C < a.H &&        \
+    (x0_) - 2 + tid % WIM_C >= 0 && (x0_) - 2 + tid % WIM_C < a.W)                                 \
+       ? (xin_)[(size_t)((y0_) - 2 + tid / WIM_C) * a.W + (x0_) - 2 + tid % WIM_C] : 0.f)
 
+  WINO_GOFS(y0, x0);
   if constexpr (STEM) {
-    if (tid < WIM_R * WIM_C) {
-      const int gy = y0 - 2 + tid / WIM_C, gx = x0 - 2 + tid % WIM_C;
-      img_s[tid] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? xin[(size_t)gy * a.W + gx] : 0.f;
-    }
+    if (tid < WIM_R * WIM_C) img_s[tid] = WINO_IMG(xin, y0, x0);
     for (int i = tid; i < 768; i += 256)
       c1_s[i] = i < 576 ? a.w1[i] : i < 640 ? a.b1[i - 576] : i < 704 ? (a.s1 ? a.s1[i - 640] : 1.f)
                                                                          : (a.t1 ? a.t1[i - 704] : 0.f);
     __syncthreads();
     WINO_FILL_IN(0);
   } else {
-    WINO_LOAD_IN(0);
+    WINO_LOAD_IN(xin, 0);
   }
-  WINO_STORE_IN(0);
+  float4 bq[4][2];
+#pragma unroll
+  for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bq[nu][nt] = wp[(nu * 2 + nt) * 64 + lane];
 
   // ---- A fragments: this wave's row transform takes patch rows a1, a2 of every tile: d[a1] + sg * d[a2] ----
   //   xi = 0: d0 - d2   xi = 1: d1 + d2   xi = 2: d2 - d1   xi = 3: d1 - d3      (B^T of F(2x2,3x3))
@@ -193,6 +219,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int o1 = (R1 * WP_C + tx) * WKC + ((h ^ (R1 & 3)) << 2);
   const int o2 = (R2 * WP_C + tx) * WKC + ((h ^ (R2 & 3)) << 2);
 
+  while (true) {
+  WINO_STORE_IN(0);
+  __syncthreads();
   f32x16 acc[4][2];
 #pragma unroll
   for (int nu = 0; nu < 4; ++nu)
@@ -200,13 +229,17 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[nu][nt][r] = 0.f;
+  const int next_item = item + gridDim.x;
+  // (the stem keeps one workgroup per item: with the next-item state live next to conv1a's 36 constant registers the
+  // kernel spills, and conv1a with fewer live constants re-reads them from LDS: -6..-10 % either way)
+  const bool more = !STEM && next_item < nitems;
+  int nx0 = 0, ny0 = 0, nbb = 0, nnb = 0;
+  const float* nxin = xin;
+  const float4* nwp = wp;
+  if (more) WINO_DECODE(next_item, nx0, ny0, nbb, nnb, nxin, nwp);
 
-  __syncthreads();
   for (int c = 0; c < nchunks; ++c) {
     const bool has_next = c + 1 < nchunks;
-    if constexpr (!STEM) {
-      if (has_next) WINO_LOAD_IN(c + 1);
-    }
     const float* ps = in_s + (c & 1) * WPATCH;
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -223,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       v[2] = f4_sub(t2, t1);
       v[3] = f4_sub(t1, t3);
       const int kg_next = 2 * c + g + 1;
-      const bool more_b = kg_next < cin / 8;
+      // next fragments: the following k group of this item, or group 0 of the next item
+      const bool more_b = (kg_next < cin / 8 || more) && !(WINO_DIAG & 2);
+      const float4* bsrc = kg_next < cin / 8 ? wp + (size_t)kg_next * 512 : nwp;
 #pragma unroll
       for (int nu = 0; nu < 4; ++nu) {
         acc[nu][0] = mfma32(v[nu].x, bq[nu][0].x, acc[nu][0]);
@@ -236,85 +271,112 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         acc[nu][1] = mfma32(v[nu].w, bq[nu][1].w, acc[nu][1]);
         // the registers of this position are free: fetch its fragments of the next k group
         if (more_b) {
-          bq[nu][0] = wp[(size_t)kg_next * 512 + (nu * 2 + 0) * 64];
-          bq[nu][1] = wp[(size_t)kg_next * 512 + (nu * 2 + 1) * 64];
+          bq[nu][0] = bsrc[(nu * 2 + 0) * 64 + lane];
+          bq[nu][1] = bsrc[(nu * 2 + 1) * 64 + lane];
         }
       }
-      if constexpr (STEM) {
-        if (g == 0 && has_next) WINO_FILL_IN(c + 1);  // VALU work under the MFMAs of this chunk
+      if (g == 0) {
+        // requested AFTER this group's fragment loads (vmcnt retires in order: the fragment waits of the next
+        // group must not include these), stored to LDS at the end of the chunk
+        if constexpr (STEM) {
+          if (has_next) { WINO_FILL_IN(c + 1); }  // VALU work under the MFMAs of this chunk
+        } else {
+          if (has_next) { WINO_LOAD_IN(xin, c + 1); }
+          else if (more) { WINO_GOFS(ny0, nx0); WINO_LOAD_IN(nxin, 0); }
+        }
       }
     }
     if (has_next) WINO_STORE_IN((c + 1) & 1);
     __syncthreads();
   }
-#undef WINO_LOAD_IN
-#undef WINO_FILL_IN
-#undef WINO_STORE_IN
 
   // ---- output transform.  Column direction (nu) lane-local: z0 = M0 + M1 + M2, z1 = M1 - M2 - M3 ----
-  float* ex = smem;  // [xi 4][j 2][nt 2][r 16][64 lanes]
+  // exchange buffer [xi 4][j 2][tile 32][cout 64]: written from the accumulator layout (cout on the lane: 128-byte
+  // runs), read back with 4 consecutive channels per lane (ds_read_b128; 16 lanes = the 256 contiguous bytes of one
+  // pixel's channel block; conflict-free at a 64-float pitch)
+  float* ex = smem;
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float m0 = acc[0][nt][r], m1 = acc[1][nt][r], m2 = acc[2][nt][r], m3 = acc[3][nt][r];
-      ex[(((xi * 2 + 0) * 2 + nt) * 16 + r) * 64 + lane] = (m0 + m1) + m2;
-      ex[(((xi * 2 + 1) * 2 + nt) * 16 + r) * 64 + lane] = (m1 - m2) - m3;
+      const int o = acc_row(r, h) * 64 + nt * 32 + l31;
+      ex[(xi * 2 + 0) * 2048 + o] = (m0 + m1) + m2;
+      ex[(xi * 2 + 1) * 2048 + o] = (m1 - m2) - m3;
     }
   __syncthreads();
-  // row direction (xi) across the waves: wave w finishes cout tile nt = w >> 1, accumulator registers 8 (w & 1) .. + 7
-  const int nt_w = xi >> 1, rh = xi & 1;
-  const int co = nb * 64 + nt_w * 32 + l31;
-  const float bi = a.bias[co];
-  const float sc = a.scale ? a.scale[co] : 1.f;
-  const float sh = a.shift ? a.shift[co] : 0.f;
+  // row direction (xi) across the waves, then bias / ReLU / BN / pool: thread -> channel quad q of tiles t, t + 16
+  const int q4 = (tid & 15) * 4;
+  const int co = nb * 64 + q4;
+  const float4 bi = *reinterpret_cast<const float4*>(a.bias + co);
+  const float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + co) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 sh = a.shift ? *reinterpret_cast<const float4*>(a.shift + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool relu = a.relu != 0;
 #pragma unroll
-  for (int rr = 0; rr < 8; ++rr) {
-    const int r = rh * 8 + rr;
-    float yv[2][2];
+  for (int k = 0; k < 2; ++k) {
+    const int tile = (tid >> 4) + 16 * k;  // Winograd tile (tile >> 2, tile & 3)
+    const float* zp = ex + tile * 64 + q4;
+    float4 yv[2][2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const float z0 = ex[(((0 * 2 + j) * 2 + nt_w) * 16 + r) * 64 + lane];
-      const float z1 = ex[(((1 * 2 + j) * 2 + nt_w) * 16 + r) * 64 + lane];
-      const float z2 = ex[(((2 * 2 + j) * 2 + nt_w) * 16 + r) * 64 + lane];
-      const float z3 = ex[(((3 * 2 + j) * 2 + nt_w) * 16 + r) * 64 + lane];
-      yv[0][j] = (z0 + z1) + z2;
-      yv[1][j] = (z1 - z2) - z3;
+      const float4 z0 = *reinterpret_cast<const float4*>(zp + (0 * 2 + j) * 2048);
+      const float4 z1 = *reinterpret_cast<const float4*>(zp + (1 * 2 + j) * 2048);
+      const float4 z2 = *reinterpret_cast<const float4*>(zp + (2 * 2 + j) * 2048);
+      const float4 z3 = *reinterpret_cast<const float4*>(zp + (3 * 2 + j) * 2048);
+      yv[0][j] = f4_add(f4_add(z0, z1), z2);
+      yv[1][j] = f4_sub(f4_sub(z1, z2), z3);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float t = yv[i][j] + bi;
-        if (a.relu) t = fmaxf(t, 0.f);
-        yv[i][j] = t * sc + sh;
+        float4 t = f4_add(yv[i][j], bi);
+        if (relu) t = make_float4(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f), fmaxf(t.z, 0.f), fmaxf(t.w, 0.f));
+        yv[i][j] = make_float4(t.x * sc.x + sh.x, t.y * sc.y + sh.y, t.z * sc.z + sh.z, t.w * sc.w + sh.w);
       }
-    const int tile = acc_row(r, h);  // Winograd tile of this register: (tile >> 2, tile & 3)
     const int oy = (y0 >> 1) + (tile >> 2), ox = (x0 >> 1) + (tile & 3);
     if constexpr (POOL) {
       const int Ho = a.H >> 1, Wo = a.W >> 1;
-      if (oy < Ho && ox < Wo)
-        a.y[(((size_t)b * Ho + oy) * Wo + ox) * a.cout + co] = fmaxf(fmaxf(yv[0][0], yv[0][1]), fmaxf(yv[1][0], yv[1][1]));
+      if (oy < Ho && ox < Wo) {
+        const float4 u = yv[0][0], v = yv[0][1], w = yv[1][0], z = yv[1][1];
+        *reinterpret_cast<float4*>(a.y + (((size_t)b * Ho + oy) * Wo + ox) * a.cout + co) =
+            make_float4(fmaxf(fmaxf(u.x, v.x), fmaxf(w.x, z.x)), fmaxf(fmaxf(u.y, v.y), fmaxf(w.y, z.y)),
+                        fmaxf(fmaxf(u.z, v.z), fmaxf(w.z, z.z)), fmaxf(fmaxf(u.w, v.w), fmaxf(w.w, z.w)));
+      }
     } else {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int gy = 2 * oy + i, gx = 2 * ox + j;
-          if (gy < a.H && gx < a.W) a.y[(((size_t)b * a.H + gy) * a.W + gx) * a.cout + co] = yv[i][j];
+          if (gy < a.H && gx < a.W)
+            *reinterpret_cast<float4*>(a.y + (((size_t)b * a.H + gy) * a.W + gx) * a.cout + co) = yv[i][j];
         }
     }
   }
+  if (!more) break;
+  item = next_item; x0 = nx0; y0 = ny0; b = nbb; nb = nnb; xin = nxin; wp = nwp;
+  __syncthreads();  // the exchange buffer has been read: the next item's first patch may land in LDS
+  }  // persistent loop over work items
+#undef WINO_DECODE
+#undef WINO_GOFS
+#undef WINO_LOAD_IN
+#undef WINO_FILL_IN
+#undef WINO_STORE_IN
+#undef WINO_IMG
 }
 
 template <bool POOL, bool STEM>
 static int launch_wino(const WinoArgs& a, hipStream_t st) {
-  constexpr size_t patches = (size_t)2 * WPATCH + (STEM ? WIM_R * WIM_C + 768 : 0), exch = 4 * 2 * 2 * 16 * 64;
-  constexpr size_t lds = (patches > exch ? patches : exch) * sizeof(float);
+  static_assert(2 * WPATCH <= 16384, "the exchange buffer covers the patch buffers");
+  constexpr size_t lds = (size_t)(16384 + (STEM ? WIM_R * WIM_C + 768 : 0)) * sizeof(float);
   static std::atomic<unsigned long long> lds_ok{0};
   if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)conv3x3_wino_kernel<POOL, STEM>, lds, lds_ok);
   const long long nitems = (long long)a.tiles_x * a.tiles_y * a.B * (a.cout / 64);
-  hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, STEM>), dim3((unsigned)nitems), dim3(256), lds, st, a);
+  const long long resident = (long long)gfc_device_cus() * 2;  // two workgroups per CU (registers, 64-68 KB LDS)
+  const int forced = gfc_knobs().conv_persist;                 // GFC_CONV_PERSIST=0: one workgroup per item
+  const long long grid = (STEM || forced == 0 || nitems < resident) ? nitems : resident;
+  hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, STEM>), dim3((unsigned)grid), dim3(256), lds, st, a);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
