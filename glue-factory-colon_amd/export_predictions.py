@@ -63,26 +63,95 @@ def _process(model, data, keys, optional_keys, callback_fn, as_half):
     return rec
 
 
+def _sharded(loader, rank, world):
+    """(index, item) of this rank's round-robin share of the loader (sharding.round_robin_shard: pairs of an
+    HPatches-style list differ in size, so consecutive pairs go to different ranks).  A loader that can skip work
+    itself may offer `shard(rank, world)` yielding (index, item); otherwise the other ranks' items are drawn and
+    dropped."""
+    if world <= 1:
+        yield from enumerate(loader)
+    elif hasattr(loader, "shard"):
+        yield from loader.shard(rank, world)
+    elif hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
+        from .sharding import round_robin_shard
+        for i in round_robin_shard(len(loader), rank, world):
+            yield i, loader[i]
+    else:
+        for i, item in enumerate(loader):
+            if i % world == rank:
+                yield i, item
+
+
+def _merge_parts(output_file, world):
+    """Rank 0: the per-rank part files -> one prediction file, records in loader order, first name wins."""
+    entries = []
+    for r in range(world):
+        part = Path(str(output_file) + f".part{r}")
+        with np.load(part, allow_pickle=False) as z:
+            recs = {}
+            for full in z.files:
+                head, key = full.rsplit("/", 1)
+                recs.setdefault(head, {})[key] = z[full]
+        for head, rec in recs.items():
+            idx, name = head.split("|", 1)
+            entries.append((int(idx), name, rec))
+        part.unlink()
+    records = {}
+    for _, name, rec in sorted(entries, key=lambda e: e[0]):
+        if name not in records:
+            records[name] = rec
+    _write(Path(output_file), records)
+
+
 @torch.no_grad()
 def export_predictions(loader, model, output_file, as_half=False, keys="*", callback_fn=None, optional_keys=(),
-                       workers=1):
+                       workers=1, rank=None, world=None):
+    """rank / world (default: the torch.distributed process group, if one is initialised): the pair list is shared
+    out round-robin over the ranks (one process per GPU, no data-path collective); every rank writes a part file
+    next to `output_file`, and after one barrier rank 0 merges them into the single prediction file the evaluation
+    reads (records in loader order, as the single-process loop writes them).  All ranks return `output_file`."""
     assert keys == "*" or isinstance(keys, (tuple, list))
     optional_keys = list(optional_keys)
     output_file = Path(output_file)
     output_file.parent.mkdir(exist_ok=True, parents=True)
+    import torch.distributed as dist
+    if world is None:
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if world > 1 else 0
     device = "cuda" if torch.cuda.is_available() else "cpu"
     model = model.to(device).eval()
+    if world > 1:
+        inner = Path(str(output_file) + f".part{rank}")
+        local = []
+        _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half, workers,
+                     local)
+        flat = {f"{idx}|{name}/{k}": v for idx, name, rec in local for k, v in rec.items()}
+        with open(inner, "wb") as fh:
+            np.savez(fh, **flat)
+        dist.barrier()
+        if rank == 0:
+            _merge_parts(output_file, world)
+        dist.barrier()
+        return output_file
+    local = []
+    _export_loop(enumerate(loader), model, device, keys, optional_keys, callback_fn, as_half, workers, local)
     records = {}
+    for _, name, rec in sorted(local, key=lambda e: e[0]):
+        if name not in records:  # like the reference: a duplicate group name is skipped
+            records[name] = rec
+    _write(output_file, records)
+    return output_file
+
+
+def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out):
+    """Process (index, item) pairs; appends (index, name, record) to `out`."""
     if workers <= 1 or device == "cpu":
-        for data_ in loader:
+        for idx, data_ in indexed:
             data = _to_device(data_, device)
             name = data.get("name", [None])[0]
-            rec = _process(model, data, keys, optional_keys, callback_fn, as_half)
-            if name in records:
-                continue  # like the reference: a duplicate group name is skipped
-            records[name] = rec
-        _write(output_file, records)
-        return output_file
+            out.append((idx, name, _process(model, data, keys, optional_keys, callback_fn, as_half)))
+        return
 
     # ---- `workers` pairs in flight: one thread + one HIP stream + one model replica each ----
     replicas = [model] + [_replicate(model) for _ in range(workers - 1)]
@@ -107,23 +176,19 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
     threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in replicas]
     for t in threads:
         t.start()
-    n = 0
-    for n, data_ in enumerate(loader, 1):
+    for idx, data_ in indexed:
         if errors:
             break
-        tasks.put((n - 1, data_))
+        tasks.put((idx, data_))
     for _ in threads:
         tasks.put(None)
     for t in threads:
         t.join()
     if errors:
         raise errors[0]
-    for idx in range(n):  # loader order, first occurrence of a name wins
+    for idx in sorted(results):
         name, rec = results[idx]
-        if name not in records:
-            records[name] = rec
-    _write(output_file, records)
-    return output_file
+        out.append((idx, name, rec))
 
 
 def _write(path: Path, records: dict):

@@ -177,12 +177,13 @@ _MATCH_MEAN = (-0.09, 0.09, -0.01, 0.00, 0.05, -0.05, 0.00, -0.53)
 _MATCH_STD = (0.06, 0.07, 0.08, 0.06, 0.09, 0.09, 0.09, 0.10)
 
 
-def lightglue_adaptive_state_dict(seed: int = 0, gain: float = 8.0, **kw):
+def lightglue_adaptive_state_dict(seed: int = 0, gain: float = 8.0, prune_z: float = 0.84, **kw):
     """Variant of `lightglue_state_dict` for exercising adaptive depth / width.  With the plain random heads
     every point of a layer lands on the same side of the thresholds (all kept or all pruned).  Here the
     token-confidence and matchability heads of layers 0..7 get a larger gain and a per-layer bias that centres
     them on the decision thresholds (confidence ~0.9, matchability ~0.05), so that per layer about half of
-    the points count as confident and roughly a fifth of those is pruned."""
+    the points count as confident and roughly a fifth of those is pruned (`prune_z`: the pruning threshold sits that
+    many standard deviations below the mean matchability logit: 0.84 -> ~20 % per layer, 1.5 -> ~7 %)."""
     sd = lightglue_state_dict(seed, **kw)
     for i in range(len(_TOKEN_MEAN)):
         k = f"token_confidence.{i}.token.0"
@@ -191,5 +192,5 @@ def lightglue_adaptive_state_dict(seed: int = 0, gain: float = 8.0, **kw):
             sd[k + ".bias"] = torch.full_like(sd[k + ".bias"], 2.2 - gain * _TOKEN_MEAN[i])
         k = f"log_assignment.{i}.matchability"
         sd[k + ".weight"] = sd[k + ".weight"] * gain
-        sd[k + ".bias"] = torch.full_like(sd[k + ".bias"], -2.94 - gain * _MATCH_MEAN[i] + 0.84 * gain * _MATCH_STD[i])
+        sd[k + ".bias"] = torch.full_like(sd[k + ".bias"], -2.94 - gain * _MATCH_MEAN[i] + prune_z * gain * _MATCH_STD[i])
     return sd

@@ -350,17 +350,82 @@ def golden_pipeline():
     save("pipeline", **out)
 
 
+# --------------------------------------------------- C3: superpoint+lightglue-official, HPatches-shaped
+from c3_inputs import C3_PAIRS, c3_pair  # noqa: E402  (tests/golden/c3_inputs.py: shared with the GPU test)
+
+
+def golden_pipeline_official():
+    """BASELINE config 3 (superpoint+lightglue-official.yaml:3-13,27-33: gluefactory_nonfree.superpoint, 1024 key
+    points, threshold 0, NMS 3 + LightGlue, filter 0.1) through the reference's TwoViewPipeline, b = 1, one record per
+    pair exactly as utils/export_predictions.py:36-85 writes it: export keys of eval/hpatches.py:61-68, key points
+    multiplied by 1 / scales (:55-61).  The official extractor's constructor fetch is redirected to the generated
+    weights; `matchers.lightglue_pretrained` needs the third-party package, so the in-tree matcher (same architecture,
+    same checkpoints) stands in for it, as everywhere else."""
+    sd = weights.superpoint_state_dict(0)
+    orig = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: sd
+    try:
+        pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": 1024,
+                                              "detection_threshold": 0.0, "nms_radius": 3},
+                                "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "flash": False,
+                                            "depth_confidence": -1, "width_confidence": -1}}).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = orig
+    pipe.matcher.load_state_dict(weights.lightglue_state_dict(0), strict=False)
+    export_keys = ["keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1",
+                   "keypoint_scores0", "keypoint_scores1"]  # eval/hpatches.py:61-68 + the optional score keys
+    out = {"names": np.array([n for n, *_ in C3_PAIRS])}
+    for i, (name, seed, s0, s1, origs) in enumerate(C3_PAIRS):
+        data = c3_pair(seed, s0, s1, origs)
+        pred = pipe(data)
+        rec = {k: pred[k] for k in export_keys}
+        for k in ("keypoints0", "keypoints1"):  # export_predictions.py:55-61
+            rec[k] = rec[k] * (1.0 / data["view" + k[-1]]["scales"])[None]
+        for k, v in rec.items():
+            out[f"p{i}_{k}"] = npy(v[0])
+        print(name, "kpts", rec["keypoints0"].shape[1], rec["keypoints1"].shape[1], "matches",
+              int((rec["matches0"] >= 0).sum()))
+    save("pipeline_official", **out)
+
+
+def golden_boat_native():
+    """C1 at its stated size (tests/test_integration.py:31-44,75-81): assets/boat1.png <-> boat2.png, 850 x 680 RGB,
+    no resize, SuperPoint-open + LightGlue through the reference's TwoViewPipeline.  The images themselves are the
+    reference's assets (data): stored as uint8 RGB."""
+    from PIL import Image
+
+    conf = {"extractor": {"name": "extractors.superpoint_open", "weights": SPO_PATH, "max_num_keypoints": 1024,
+                          "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "flash": False}}
+    pipe = TwoViewPipeline(conf).eval()
+    pipe.matcher.load_state_dict(weights.lightglue_state_dict(0), strict=False)
+    out = {}
+    views = {}
+    for i, name in enumerate(("boat1.png", "boat2.png")):
+        a = np.asarray(Image.open(os.path.join(REF, "assets", name)).convert("RGB"), dtype=np.uint8)
+        out[f"image{i}"] = a  # [680, 850, 3]
+        t = torch.from_numpy(a.astype(np.float32) / 255).permute(2, 0, 1)[None].contiguous()
+        views[f"view{i}"] = {"image": t, "image_size": torch.tensor([[float(a.shape[1]), float(a.shape[0])]])}
+    pred = pipe(views)
+    for key in ("keypoints0", "keypoints1", "keypoint_scores0", "keypoint_scores1", "matches0", "matches1",
+                "matching_scores0", "matching_scores1"):
+        out[key] = npy(pred[key])
+    print("boat native", out["image0"].shape, "matches", int((pred["matches0"] >= 0).sum()))
+    save("boat_native", **out)
+
+
 def golden_lightglue_adaptive():
     """Adaptive width (point pruning) and the depth check on a run that reaches the last layer
-    (lightglue.py:500-536,555-580); b == 1."""
-    h, w, k = 120, 160, 160
+    (lightglue.py:500-536,555-580); b == 1.  512 key points per image and a pruning rate of ~7 % per layer, so that
+    the index scatter back to the un-pruned numbering is exercised on a few hundred surviving points and matches."""
+    h, w, k = 240, 320, 512
     v0, v1, p0, p1 = _features(1, h, w, k, seed=31)
     size = torch.tensor([[w, h]], dtype=torch.float32)
     data = {"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"], "descriptors0": p0["descriptors"],
             "descriptors1": p1["descriptors"], "view0": {"image_size": size}, "view1": {"image_size": size}}
     out = {"keypoints0": npy(p0["keypoints"]), "keypoints1": npy(p1["keypoints"]),
            "descriptors0": npy(p0["descriptors"]), "descriptors1": npy(p1["descriptors"]), "image_size": npy(size)}
-    sd = weights.lightglue_adaptive_state_dict(0)
+    sd = weights.lightglue_adaptive_state_dict(0, prune_z=ADAPTIVE_PRUNE_Z)
     for tag, conf in (("prune", {"width_confidence": 0.95}),
                       ("both", {"width_confidence": 0.95, "depth_confidence": 0.95})):
         m = ref_lg.LightGlue({"filter_threshold": 0.1, **conf}).eval()
@@ -372,6 +437,9 @@ def golden_lightglue_adaptive():
         print(tag, "kept", pred["log_assignment"].shape, "matches", int((pred["matches0"] >= 0).sum()),
               "prune0 hist", torch.bincount(pred["prune0"][0].long()).tolist())
     save("lightglue_adaptive", **out)
+
+
+ADAPTIVE_PRUNE_Z = 1.5  # tests/test_gpu_models.py builds the same weights
 
 
 def golden_nn_matcher():
@@ -439,6 +507,15 @@ def golden_scale_ori():
 
 
 if __name__ == "__main__":
+    if "--only-official-pipeline" in sys.argv:
+        golden_pipeline_official()
+        sys.exit(0)
+    if "--only-boat-native" in sys.argv:
+        golden_boat_native()
+        sys.exit(0)
+    if "--only-adaptive" in sys.argv:
+        golden_lightglue_adaptive()
+        sys.exit(0)
     if "--only-scale-ori" in sys.argv:
         golden_scale_ori()
         sys.exit(0)
@@ -456,3 +533,5 @@ if __name__ == "__main__":
     golden_superpoint_official()
     golden_lightglue()
     golden_pipeline()
+    golden_pipeline_official()
+    golden_boat_native()

@@ -32,7 +32,7 @@ def _key(kp):
 
 
 def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, tie_tol=2e-6, score_tol=1e-5,
-                      desc_tol=1e-4, max_flip_frac=0.02):
+                      desc_tol=1e-4, max_flip_frac=0.0):
     """kp [N,2], sc [N], desc [N,D] (HIP) vs reference lists.  Returns (idx_mine, idx_ref) of the common points."""
     kp, sc, desc = kp.cpu(), sc.cpu(), desc.cpu()
     assert kp.shape == ref_kp.shape, (kp.shape, ref_kp.shape)  # counts are exact
@@ -43,6 +43,8 @@ def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, ti
     im = torch.tensor([mine[k] for k in common], dtype=torch.long)
     ir = torch.tensor([ref[k] for k in common], dtype=torch.long)
     n_flip = len(ref) - len(common)
+    # measured on every case of the suite (profiles/r02_parity_stats.json): 0 flips.  One flip stays admissible -- it
+    # must still be EXPLAINED below as a near tie at the selection boundary or inside one NMS window.
     assert n_flip <= max_flip_frac * max(len(ref), 1) + 1, f"{name}: {n_flip} of {len(ref)} key points differ"
     s_err = (sc[im] - ref_sc[ir]).abs().max().item() if len(common) else 0.0
     d_err = (desc[im] - ref_desc[ir]).abs().max().item() if len(common) else 0.0

@@ -64,7 +64,7 @@ def test_c2_batch32_vs_oracle(c2_batch32):
         assert okp.shape == (2, K, 2)  # every image of this workload has more than K detections: no padding
         for side, p in ((0, p0), (1, p1)):
             compare_keypoints(f"c2_b32_pair{i}_view{side}", p["keypoints"][i], p["keypoint_scores"][i],
-                              p["descriptors"][i], okp[side], osc[side], ode[side], radius=3, max_flip_frac=0.002)
+                              p["descriptors"][i], okp[side], osc[side], ode[side], radius=3)
         ref = olg.match(sd_lg, okp[:1], okp[1:], ode[:1], ode[1:], size, size, filter_threshold=0.1)
         mine = match_pairs(p0["keypoints"][i], p1["keypoints"][i], out["matches0"][i])
         theirs = match_pairs(okp[0], okp[1], ref["matches0"][0])

@@ -400,8 +400,9 @@ def test_lightglue_adaptive_golden_and_early_stop(golden):
     """Adaptive width against the reference's vectors; adaptive depth (early stop) against the oracle
     (the reference's in-tree class cannot return from an early stop in eval mode, see oracle docstring)."""
     g = golden("lightglue_adaptive")
-    sd = weights.lightglue_adaptive_state_dict(0)
+    sd = weights.lightglue_adaptive_state_dict(0, prune_z=1.5)  # as tests/golden/make_golden.py (ADAPTIVE_PRUNE_Z)
     data = lg_data(g)
+    assert g["prune_log_assignment"].shape[1] > 200 and int((g["prune_matches0"] >= 0).sum()) > 100  # a rich case
     for tag, conf in (("prune", dict(width_confidence=0.95)), ("both", dict(width_confidence=0.95, depth_confidence=0.95))):
         m = lightglue.LightGlue({"filter_threshold": 0.1, **conf}).eval()
         m.load_state_dict(sd, strict=False)
@@ -510,6 +511,33 @@ def test_pipeline_golden(golden):
             assert (pred["matches0"] >= 0).sum() > 50
 
 
+def test_boat_pair_native_size_golden(golden):
+    """BASELINE config 1 at its stated size (tests/test_integration.py:31-44: assets/boat1.png <-> boat2.png, 850 x 680
+    RGB, no resize): SuperPoint-open + LightGlue through the pipeline against the reference pipeline's outputs.
+    (With name-seeded weights the matcher finds no match on this wide-baseline pair -- neither does the reference;
+    key points, their scores and the matching scores are what is compared.)"""
+    g = golden("boat_native")
+    conf = {"extractor": {**PIPE_CONF["extractor"], "max_num_keypoints": 1024}, "matcher": PIPE_CONF["matcher"]}
+    pipe = TwoViewPipeline(conf).eval().to(DEV)
+    views = {}
+    for i in "01":
+        a = g["image" + i]  # [680, 850, 3] uint8
+        assert tuple(a.shape) == (680, 850, 3)
+        t = (a.float() / 255).permute(2, 0, 1)[None].contiguous().to(DEV)
+        views["view" + i] = {"image": t, "image_size": torch.tensor([[850.0, 680.0]], device=DEV)}
+    pred = pipe(views)
+    for i in "01":
+        kp, ref = pred["keypoints" + i][0].cpu(), g["keypoints" + i][0]
+        assert kp.shape == ref.shape == (1024, 2)
+        assert set(map(tuple, kp.tolist())) == set(map(tuple, ref.tolist())), i
+        order = {tuple(q): j for j, q in enumerate(kp.tolist())}
+        perm = torch.tensor([order[tuple(q)] for q in ref.tolist()])
+        assert maxerr(pred["keypoint_scores" + i][0].cpu()[perm], g["keypoint_scores" + i][0]) < TOL
+        assert maxerr(pred["matching_scores" + i][0].cpu()[perm], g["matching_scores" + i][0]) < TOL
+    assert match_pairs(pred["keypoints0"][0], pred["keypoints1"][0], pred["matches0"][0]) == \
+        match_pairs(g["keypoints0"][0], g["keypoints1"][0], g["matches0"][0])
+
+
 # ---------------------------------------------------------------- full size (BASELINE C2)
 @pytest.fixture(scope="module")
 def vga_case():
@@ -566,7 +594,8 @@ def test_vga_1024_against_oracle(vga_case):
         mine = match_pairs(p["keypoints"][b], p["keypoints"][2 + b], pred["matches0"][b])
         theirs = match_pairs(okp[b], okp[2 + b], ref["matches0"][b])
         agree += len(mine & theirs)
-        assert len(mine ^ theirs) <= 0.02 * len(theirs) + 2, (len(mine), len(theirs), len(mine & theirs))
+        # measured: identical pair sets (1485 of 1485); one explained key-point near-tie may move one pair
+        assert len(mine ^ theirs) <= 2, (len(mine), len(theirs), len(mine & theirs))
     record("vga_k1024_matches", ref_matches=n_ref, agree=agree, log_assignment_rel_err=float(la_err))
     # size-independent properties
     m0, m1 = pred["matches0"], pred["matches1"]

@@ -270,3 +270,51 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
     # mismatch between --gpus and an inherited WORLD_SIZE is an error, not a silent single-rank run
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
     assert r.returncode != 0
+
+
+def test_export_predictions_sharded_world2_gloo(tmp_path):
+    """HPatches-style export shared out over 2 ranks (round-robin over the pair list, one part file per rank, one
+    barrier, rank 0 merges): the merged file equals the single-process export -- same record names in loader order,
+    same arrays, key points un-scaled by 1 / scales (reference utils/export_predictions.py:36-85).  Fake model on CPU."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, torch, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from glue_factory_colon_amd import sharding\n"
+        "from glue_factory_colon_amd.export_predictions import export_predictions, load_predictions\n"
+        "class Fake(torch.nn.Module):\n"
+        "    def forward(self, data):\n"
+        "        k0 = data['view0']['x'] * 2 + 1\n"
+        "        return {'keypoints0': k0, 'keypoints1': data['view1']['x'], 'matches0': (k0[..., 0] > 3).long() - 1,\n"
+        "                'matching_scores0': k0[..., 1], 'unused': k0}\n"
+        "def item(i):\n"
+        "    g = torch.Generator().manual_seed(i)\n"
+        "    n = 5 + i % 3\n"
+        "    v = lambda: {'x': torch.rand((1, n, 2), generator=g) * 9, 'scales': torch.tensor([[0.5 + 0.1 * i, 0.75]])}\n"
+        "    return {'name': [f'v_seq{i // 3}/{i % 3 + 2}.ppm'], 'view0': v(), 'view1': v()}\n"
+        "items = [item(i) for i in range(7)]\n"
+        "items.append({**item(1)})  # duplicate name: the first occurrence wins\n"
+        "keys = ['keypoints0', 'keypoints1', 'matches0', 'matching_scores0']\n"
+        "rank, world, _ = sharding.init_from_env('gloo')\n"
+        "out = sys.argv[1]\n"
+        "export_predictions(items, Fake(), out + '/sharded.npz', keys=keys)\n"
+        "if rank == 0:\n"
+        "    export_predictions(items, Fake(), out + '/single.npz', keys=keys, rank=0, world=1)\n"
+        "    a, b = load_predictions(out + '/sharded.npz'), load_predictions(out + '/single.npz')\n"
+        "    assert list(a) == list(b) == [f'v_seq{i // 3}/{i % 3 + 2}.ppm' for i in range(7)], list(a)\n"
+        "    for n in a:\n"
+        "        assert sorted(a[n]) == sorted(keys)\n"
+        "        for k in keys:\n"
+        "            assert np.array_equal(a[n][k], b[n][k]), (n, k)\n"
+        "    it = items[4]\n"
+        "    ref = (it['view0']['x'][0] * 2 + 1) * (1.0 / it['view0']['scales'])\n"
+        "    assert np.array_equal(a[it['name'][0]]['keypoints0'], ref.numpy())\n"
+        "    import os; assert not [f for f in os.listdir(out) if '.part' in f]\n"
+        "    print('SHARDED_EXPORT_OK')\n"
+        "torch.distributed.barrier()\n")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0 and "SHARDED_EXPORT_OK" in r.stdout, r.stdout + r.stderr

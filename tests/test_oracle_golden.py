@@ -192,13 +192,13 @@ def test_lightglue_add_scale_ori(golden):
 def test_lightglue_adaptive_pruning(golden):
     """Point pruning (and the depth check on a run that reaches the last layer) against the reference."""
     g = golden("lightglue_adaptive")
-    sd = weights.lightglue_adaptive_state_dict(0)
+    sd = weights.lightglue_adaptive_state_dict(0, prune_z=1.5)  # as make_golden.py (ADAPTIVE_PRUNE_Z)
     size = g["image_size"]
     for tag, conf in (("prune", dict(width_confidence=0.95)), ("both", dict(width_confidence=0.95, depth_confidence=0.95))):
         out = olg.match_adaptive(sd, g["keypoints0"], g["keypoints1"], g["descriptors0"], g["descriptors1"], size, size,
                                  filter_threshold=0.1, **conf)
         assert out["log_assignment"].shape == g[f"{tag}_log_assignment"].shape  # same surviving point counts
-        assert out["log_assignment"].shape[1] < 161 and out["stop_layer"] == 9
+        assert out["log_assignment"].shape[1] < 513 and out["stop_layer"] == 9
         for key in ("matches0", "matches1", "prune0", "prune1"):
             assert torch.equal(out[key], g[f"{tag}_{key}"]), (tag, key)
         close(out["matching_scores0"], g[f"{tag}_matching_scores0"], 1e-4)
