@@ -107,6 +107,10 @@ SIGNATURES = {
     "gfc_conv3x3_wino": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "gfc_sp_stem_wino": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "gfc_disk_select_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_disk_nms_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gfc_disk_gather_descriptors": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "gfc_sp_refine_keypoints": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "gfc_sp_mask_scores": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p] * 2),
     "gfc_sp_filter_keypoints": (c_int, [c_void_p] * 3 + [c_int] * 2 + [c_void_p] + [c_int] * 2 + [c_void_p, c_float, c_void_p]),

@@ -18,6 +18,9 @@ ALIASES = {
     "lightglue_pretrained": "lightglue_pretrained",
     "matchers.nearest_neighbor_matcher": "nearest_neighbor_matcher",
     "nearest_neighbor_matcher": "nearest_neighbor_matcher",
+    "extractors.disk_kornia": "disk_kornia",
+    "disk_kornia": "disk_kornia",
+    "gluefactory.models.extractors.disk_kornia": "disk_kornia",
     "two_view_pipeline": "two_view_pipeline",
     "cache_loader": "cache_loader",
 }

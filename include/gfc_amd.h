@@ -228,6 +228,23 @@ int gfc_sp_sample(const float* desc_raw, int B, int h, int w, int D, const float
 int gfc_l2norm_rows(float* x, long long rows, int width, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * DISK extractor: the stages behind the network (disk_kornia.py:42-47,129-137; kornia's
+ * heatmap_to_keypoints / nms / merge_with_descriptors restated: parity for them is unpinned, kornia is absent)
+ * ---------------------------------------------------------------------------------- */
+/* heat-map [B,H,W] -> key points.  A pixel survives iff it is the first maximum (row-major window scan, as
+ * F.max_pool2d(return_indices=True) reports it) of the window x window neighbourhood centred on it and > cutoff.
+ * n >= 0: keep the scores strictly above the (n+1)-th largest survivor (min(n+1, count)-th: with count <= n the
+ * minimum is dropped), first n in row-major order; n < 0: all survivors.  kpts [B,cap,2] (x,y as floats, integer
+ * valued, NOT sorted by score), kscores [B,cap], counts [B].  cap >= n (n >= 0) or >= H*W.  window odd, <= 9. */
+size_t gfc_disk_select_workspace_bytes(int B, int H, int W);
+int gfc_disk_nms_select(const float* heatmap, int B, int H, int W, int window, float cutoff, int n, int cap,
+                        float* kpts, float* kscores, int32_t* counts, void* ws, size_t ws_bytes, void* stream);
+/* dense descriptors [B,D,H,W] (NCHW) read at the integer key-point pixels and L2-normalised over D
+ * (F.normalize, eps 1e-12) -> out [B,cap,D]; slots >= counts[b] (counts nullable) are zero-filled. */
+int gfc_disk_gather_descriptors(const float* dense_nchw, int B, int D, int H, int W, const float* kpts,
+                                const int32_t* counts, int cap, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * LightGlue matcher
  * ---------------------------------------------------------------------------------- */
 #define GFC_LG_MAX_LAYERS 16

@@ -214,3 +214,28 @@ def test_nn_matcher(golden):
             assert torch.equal(out[key], g[f"{tag}_{key}"]), (tag, key)
     close(out["similarity"], g["similarity"], 1e-6)
     close(olg.nn_match(g["descriptors0"], g["descriptors1"])["log_assignment"], g["log_assignment"], 1e-5)
+
+
+def test_disk_oracle_known_answers():
+    """oracle/disk.py restates kornia's detection functions (kornia is absent: parity unpinned).  Hand-checkable cases:
+    first-maximum tie rule of max_pool2d(return_indices), strict cutoff, the (n+1)-th-score threshold (which drops the
+    minimum when there are not more than n candidates), row-major output order, descriptor normalisation."""
+    from oracle import disk as odisk
+
+    s = torch.full((1, 1, 7, 9), -1.0)
+    s[0, 0, 2, 2] = 0.5
+    s[0, 0, 2, 3] = 0.5      # tie inside one window: only the first (row-major) maximum survives
+    s[0, 0, 5, 7] = 0.25
+    s[0, 0, 0, 8] = 0.0      # not > cutoff 0
+    keep = odisk.window_nms(s.squeeze(1), 5, 0.0)
+    assert keep.nonzero().tolist() == [[0, 2, 2], [0, 5, 7]]
+    (xy, sc), = odisk.heatmap_to_keypoints(s, None, 5, 0.0)
+    assert xy.tolist() == [[2, 2], [7, 5]] and sc.tolist() == [0.5, 0.25]
+    (xy, sc), = odisk.heatmap_to_keypoints(s, 1, 5, 0.0)      # 2 candidates > n = 1: the best one
+    assert xy.tolist() == [[2, 2]]
+    (xy, sc), = odisk.heatmap_to_keypoints(s, 2, 5, 0.0)      # 2 candidates <= n: the minimum is dropped (kornia)
+    assert xy.tolist() == [[2, 2]]
+    dense = torch.zeros((4, 7, 9))
+    dense[:, 2, 2] = torch.tensor([3.0, 0.0, 4.0, 0.0])
+    d = odisk.merge_with_descriptors(torch.tensor([[2, 2], [0, 0]]), dense)
+    assert torch.allclose(d[0], torch.tensor([0.6, 0.0, 0.8, 0.0])) and (d[1] == 0).all()
