@@ -37,7 +37,7 @@
 #define WIM_R 20                   // STEM: image patch rows
 #define WIM_C 12                   // STEM: image patch columns
 #ifndef WINO_DIAG
-#define WINO_DIAG 0                // diagnostic builds (tools/ab_build.sh): 1 no conv1a, 2 no B reloads, 4 no epilogue, 8 no patch loads
+#define WINO_DIAG 0                // diagnostic builds (tools/ab_build.sh): 1 no conv1a, 2 no B reloads, 8 no patch loads, 16 no column transform, 64 no chunk barrier
 #endif
 
 struct WinoArgs {
@@ -251,10 +251,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       const float4 t2 = f4_axpy(sg, *reinterpret_cast<const float4*>(p2 + 1 * WKC), *reinterpret_cast<const float4*>(p1 + 1 * WKC));
       const float4 t3 = f4_axpy(sg, *reinterpret_cast<const float4*>(p2 + 6 * WKC), *reinterpret_cast<const float4*>(p1 + 6 * WKC));
       float4 v[4];
-      v[0] = f4_sub(t0, t2);
-      v[1] = f4_add(t1, t2);
-      v[2] = f4_sub(t2, t1);
-      v[3] = f4_sub(t1, t3);
+      if (WINO_DIAG & 16) {  // diagnostic: fragments without the column transform
+        v[0] = t0; v[1] = t1; v[2] = t2; v[3] = t3;
+      } else {
+        v[0] = f4_sub(t0, t2);
+        v[1] = f4_add(t1, t2);
+        v[2] = f4_sub(t2, t1);
+        v[3] = f4_sub(t1, t3);
+      }
       const int kg_next = 2 * c + g + 1;
       // next fragments: the following k group of this item, or group 0 of the next item
       const bool more_b = (kg_next < cin / 8 || more) && !(WINO_DIAG & 2);
@@ -287,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       }
     }
     if (has_next) WINO_STORE_IN((c + 1) & 1);
-    __syncthreads();
+    if (!(WINO_DIAG & 64)) __syncthreads();
   }
 
   // ---- output transform.  Column direction (nu) lane-local: z0 = M0 + M1 + M2, z1 = M1 - M2 - M3 ----

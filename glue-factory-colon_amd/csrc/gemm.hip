@@ -41,7 +41,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
                                               int n0, int wm, int wn, int lane, int wave) {
   constexpr int WT = 32 * MT;
   const int l31 = lane & 31, h = lane >> 5;
-  if (g.rot_cos == nullptr && g.residual == nullptr) {
+  // (workgroup-uniform: column tiles at or beyond rot_cols -- the V third of the fused QKV projection -- carry no
+  // rotary and take the direct path as well)
+  if ((g.rot_cos == nullptr || n0 >= g.rot_cols) && g.residual == nullptr) {
     // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
     // measured faster than the LDS transpose below when nothing has to be loaded per element
 #pragma unroll
