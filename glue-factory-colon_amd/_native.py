@@ -84,6 +84,8 @@ SIGNATURES = {
                           + [c_void_p] * 5 + [c_size_t, c_void_p]),
     "gfc_sp_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p,
                               c_void_p, c_void_p]),
+    "gfc_sp_pad_keypoints": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int,
+                                     c_float, ctypes.c_uint, c_void_p]),
     "gfc_l2norm_rows": (c_int, [c_void_p, c_longlong, c_int, c_void_p]),
     "gfc_lg_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_lg_posenc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,

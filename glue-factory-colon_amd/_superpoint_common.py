@@ -112,6 +112,29 @@ class PackedSuperPoint:
         self.device = device
 
 
+def pad_keypoints_native(kpts, scores, counts, k, low, data, image):
+    """`pad_random_c` as ONE launch (gfc_sp_pad_keypoints), in place on the selection kernel's [B,cap] outputs; returns
+    the [B,k] views."""
+    lib = nat.lib()
+    b, cap, _ = kpts.shape
+    sizes = None
+    if "image_size" in data:
+        sizes = data["image_size"].to(device=kpts.device, dtype=torch.float32).contiguous()
+    # seed = (seed, offset) of torch's device generator, whose offset is advanced like a consumer of randomness would:
+    # reproducible under torch.manual_seed, no kernel launch, no synchronisation
+    gen = torch.cuda.default_generators[kpts.device.index if kpts.device.index is not None else torch.cuda.current_device()]
+    offset = gen.get_offset()
+    gen.set_offset(offset + 4)
+    seed = (gen.initial_seed() * 0x9E3779B1 + offset * 0x85EBCA77 + 1) & 0xFFFFFFFF
+    nat.check(lib.gfc_sp_pad_keypoints(nat.ptr(kpts), nat.ptr(scores), nat.ptr(counts), b, cap, int(k), float(low),
+                                       nat.ptr(sizes), 0 if sizes is None else sizes.numel(),
+                                       float(min(image.shape[-2:])), seed, nat.stream_ptr(kpts.device)),
+              "gfc_sp_pad_keypoints")
+    if cap == k:
+        return kpts, scores
+    return kpts[:, :k].contiguous(), scores[:, :k].contiguous()
+
+
 def pad_random_c(kpts, scores, counts, k, low, high):
     """`pad_and_stack(..., mode="random_c")` + zeros for the scores, on the device and without a
     host synchronisation (gluefactory/models/utils/misc.py:19-62,103-113): slots >= count are
@@ -286,9 +309,8 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
     if force_num_keypoints:
         if k is None:
             raise ValueError("force_num_keypoints needs max_num_keypoints")
-        # kept on the device: no host synchronisation on the batched path
-        bound = data["image_size"].min() if "image_size" in data else min(image.shape[-2:])
-        kpts, ksc = pad_random_c(kpts, ksc, counts, k, 0, bound)
+        # kept on the device: no host synchronisation on the batched path, one launch
+        kpts, ksc = pad_keypoints_native(kpts, ksc, counts, k, 0, data, image)
         counts_arg = None
     else:
         n = counts.tolist()  # host sync, as torch.where in the reference

@@ -60,7 +60,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         for (int r = 0; r < 16; ++r) {
           const int row = m0 + wm * WT + mt * 32 + acc_row(r, h);
           float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 1)
+          if (row < g.M && col_ok && v == 12345.678f) Y[(size_t)row * g.ldy + col] = v;  // diagnostic: no stores
+#else
           if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
+#endif
         }
       }
     }

@@ -745,3 +745,71 @@ extern "C" int gfc_sp_refine_keypoints(const float* heatmap, int B, int H, int W
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// pad_and_stack(..., mode="random_c") + zeros for the scores (gluefactory/models/utils/misc.py:19-62,103-113, called
+// with force_num_keypoints at superpoint_open.py:193-219 / superpoint.py:330-365 / disk_kornia.py:109-124): slots at
+// or beyond an image's count get, per coordinate, a uniform sample in [min, max] of the image's own key points (the
+// fallback bounds [low, high] when it has none); their scores become 0.  One workgroup per image, in place.
+// The samples come from a counter-based generator keyed by (seed, image, slot, coordinate): the reference draws
+// them from torch's CPU generator, so the values differ by construction -- they are random padding there too.
+// high = min over `sizes` (n_sizes floats: data["image_size"].min()) when given, else `high_fallback`.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pad_uniform(unsigned int a, unsigned int b, unsigned int c, unsigned int d) {
+  unsigned int x = a * 0x9E3779B1u ^ (b + 0x7F4A7C15u) * 0x85EBCA77u ^ (c + 0x165667B1u) * 0xC2B2AE3Du ^ d * 0x27D4EB2Fu;
+  x ^= x >> 15; x *= 0x2C1B3C6Du; x ^= x >> 12; x *= 0x297A2D39u; x ^= x >> 15;  // lowbias32-style finaliser
+  return (float)(x >> 8) * (1.0f / 16777216.0f);                                 // [0, 1)
+}
+
+__global__ __launch_bounds__(256) void pad_keypoints_kernel(float* __restrict__ kpts, float* __restrict__ kscores,
+                                                            const int* __restrict__ counts, int cap, int k, float low,
+                                                            const float* __restrict__ sizes, int n_sizes,
+                                                            float high_fallback, unsigned int seed) {
+  __shared__ float red[4][4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* kp = kpts + (size_t)b * cap * 2;
+  float* ks = kscores + (size_t)b * cap;
+  const int n = min(counts[b], k);
+  if (n >= k) return;  // nothing to pad (workgroup-uniform)
+  float mnx = INFINITY, mny = INFINITY, mxx = -INFINITY, mxy = -INFINITY;
+  for (int i = tid; i < n; i += 256) {
+    const float x = kp[2 * i], y = kp[2 * i + 1];
+    mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o)); mny = fminf(mny, __shfl_xor(mny, o));
+    mxx = fmaxf(mxx, __shfl_xor(mxx, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+  }
+  if (lane == 0) { red[wave][0] = mnx; red[wave][1] = mny; red[wave][2] = mxx; red[wave][3] = mxy; }
+  __syncthreads();
+  mnx = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+  mny = fminf(fminf(red[0][1], red[1][1]), fminf(red[2][1], red[3][1]));
+  mxx = fmaxf(fmaxf(red[0][2], red[1][2]), fmaxf(red[2][2], red[3][2]));
+  mxy = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+  if (n == 0) {  // the bounds are the fallback for an empty sequence (misc.py:47-49)
+    float high = high_fallback;
+    if (sizes) {
+      high = INFINITY;
+      for (int i = 0; i < n_sizes; ++i) high = fminf(high, sizes[i]);
+    }
+    mnx = mny = low;
+    mxx = mxy = high;
+  }
+  for (int i = n + tid; i < k; i += 256) {
+    kp[2 * i] = mnx + pad_uniform(seed, (unsigned)b, (unsigned)i, 0u) * (mxx - mnx);
+    kp[2 * i + 1] = mny + pad_uniform(seed, (unsigned)b, (unsigned)i, 1u) * (mxy - mny);
+    ks[i] = 0.f;
+  }
+}
+
+extern "C" int gfc_sp_pad_keypoints(float* kpts, float* kscores, const int32_t* counts, int B, int cap, int k, float low,
+                                    const float* sizes, int n_sizes, float high_fallback, unsigned int seed,
+                                    void* stream) {
+  if (!kpts || !kscores || !counts || B <= 0 || k <= 0 || cap < k || (sizes && n_sizes <= 0)) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(pad_keypoints_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, kpts, kscores, counts, cap, k, low,
+                     sizes, n_sizes, high_fallback, seed);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}

@@ -23,7 +23,7 @@ import time
 import torch
 
 from . import _native as nat
-from ._superpoint_common import pad_random_c, specular_mask_bytes
+from ._superpoint_common import pad_keypoints_native, specular_mask_bytes
 from .base_model import BaseModel, conf_get
 
 
@@ -140,8 +140,7 @@ class DISK(BaseModel):
                                                           nat.ptr(counts[i:i + dn.shape[0]]), cap,
                                                           nat.ptr(desc[i:i + dn.shape[0]]), st), "gfc_disk_gather_descriptors")
             if force:
-                bound = data["image_size"].min() if "image_size" in data else min(image.shape[-2:])
-                kpts, ksc = pad_random_c(kpts, ksc, counts, n_out, 0, bound)  # disk_kornia.py:109-124
+                kpts, ksc = pad_keypoints_native(kpts, ksc, counts, n_out, 0, data, image)  # disk_kornia.py:109-124
             kpts, ksc, desc = kpts[:, :n_out], ksc[:, :n_out], desc[:, :n_out]
         pred = {
             "keypoints": kpts.contiguous().to(image) + 0.5,

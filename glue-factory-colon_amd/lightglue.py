@@ -276,13 +276,20 @@ class LightGlue(nn.Module):
             so0, so1 = pack(data["scales0"], data["oris0"]), pack(data["scales1"], data["oris1"])
         if (conf.depth_confidence > 0 or conf.width_confidence > 0) and m > 0 and n > 0:
             return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1, so0, so1)
-        m0 = torch.full((b, m), -1, device=device, dtype=torch.long)
-        m1 = torch.full((b, n), -1, device=device, dtype=torch.long)
-        ms0 = torch.zeros((b, m), device=device)
-        ms1 = torch.zeros((b, n), device=device)
-        scores = torch.zeros((b, m + 1, n + 1), device=device)
-        ref0 = torch.zeros((b, 1, m, conf.descriptor_dim), device=device)
-        ref1 = torch.zeros((b, 1, n, conf.descriptor_dim), device=device)
+        if m > 0 and n > 0:  # every element of the outputs is written by gfc_lg_forward: no fills
+            alloc = torch.empty
+        else:                # the reference's early return (lightglue.py:298-303): all -1 / zeros
+            alloc = torch.zeros
+        m0 = alloc((b, m), device=device, dtype=torch.long)
+        m1 = alloc((b, n), device=device, dtype=torch.long)
+        if not (m > 0 and n > 0):
+            m0.fill_(-1)
+            m1.fill_(-1)
+        ms0 = alloc((b, m), device=device)
+        ms1 = alloc((b, n), device=device)
+        scores = alloc((b, m + 1, n + 1), device=device)
+        ref0 = alloc((b, 1, m, conf.descriptor_dim), device=device)
+        ref1 = alloc((b, 1, n, conf.descriptor_dim), device=device)
         if m > 0 and n > 0:
             if self._packed is None or self._packed[2] != device:
                 self._packed = self._pack(device)
@@ -306,8 +313,8 @@ class LightGlue(nn.Module):
             "ref_descriptors0": ref0,
             "ref_descriptors1": ref1,
             "log_assignment": scores,
-            "prune0": torch.ones_like(ms0) * conf.n_layers,
-            "prune1": torch.ones_like(ms1) * conf.n_layers,
+            "prune0": torch.full_like(ms0, conf.n_layers),
+            "prune1": torch.full_like(ms1, conf.n_layers),
         }
 
     # -- adaptive depth / width (lightglue.py:500-521,555-580) -----------------------------------

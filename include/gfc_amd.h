@@ -224,6 +224,14 @@ int gfc_sp_nms_select(const float* heatmap, int B, int H, int W, int radius, int
 int gfc_sp_sample(const float* desc_raw, int B, int h, int w, int D, const float* kpts, const int32_t* n_kpts,
                   int cap, int mode, float* out, float* kpts_out, void* stream);
 
+/* pad_and_stack(mode="random_c") for key points + zeros for their scores, in place, one launch, no host sync
+ * (gluefactory/models/utils/misc.py:19-62,103-113; force_num_keypoints at superpoint_open.py:193-219,
+ * superpoint.py:330-365, disk_kornia.py:109-124): slots in [counts[b], k) get per-coordinate uniform samples in
+ * [min, max] of the image's own key points ([low, high] when it has none; high = min over `sizes` if given, else
+ * high_fallback) from a counter-based generator keyed by (seed, image, slot) -- random padding, as in the reference. */
+int gfc_sp_pad_keypoints(float* kpts, float* kscores, const int32_t* counts, int B, int cap, int k, float low,
+                         const float* sizes, int n_sizes, float high_fallback, unsigned int seed, void* stream);
+
 /* L2-normalise rows in place (dense_outputs: F.normalize over channels, superpoint_open.py:133-135). */
 int gfc_l2norm_rows(float* x, long long rows, int width, void* stream);
 

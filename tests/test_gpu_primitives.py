@@ -1007,3 +1007,37 @@ def test_assignment_tail_variants_via_knob():
                         "assignment_head_two_pass", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
+
+
+def test_pad_keypoints_random_c():
+    """gfc_sp_pad_keypoints = pad_and_stack(mode="random_c") + zero scores in one launch (models/utils/misc.py:19-62):
+    valid entries untouched, padded coordinates inside [min, max] of the image's own key points per column (fallback
+    bounds for an empty image), padded scores 0, reproducible under torch.manual_seed."""
+    from glue_factory_colon_amd._superpoint_common import pad_keypoints_native
+
+    g = gen(8)
+    b, k = 4, 300
+    kp = torch.rand((b, k, 2), generator=g) * torch.tensor([600.0, 400.0]) + 20
+    sc = torch.rand((b, k), generator=g) + 0.1
+    counts = torch.tensor([k, 120, 0, 1], dtype=torch.int32)
+    img = torch.zeros((b, 1, 480, 640), device=DEV)
+    data = {"image_size": torch.tensor([[640.0, 480.0], [500.0, 470.0], [640.0, 333.0], [640.0, 480.0]], device=DEV)}
+
+    def run(seed):
+        torch.manual_seed(seed)
+        a, s_ = pad_keypoints_native(kp.clone().to(DEV), sc.clone().to(DEV), counts.to(DEV), k, 0, data, img)
+        torch.cuda.synchronize()
+        return a.cpu(), s_.cpu()
+
+    a, s_ = run(3)
+    assert torch.equal(a[0], kp[0]) and torch.equal(s_[0], sc[0])                       # full image: untouched
+    assert torch.equal(a[1, :120], kp[1, :120]) and torch.equal(s_[1, :120], sc[1, :120])
+    lo, hi = kp[1, :120].amin(0), kp[1, :120].amax(0)
+    assert (a[1, 120:] >= lo).all() and (a[1, 120:] <= hi).all() and (s_[1, 120:] == 0).all()
+    assert a[1, 120:].std(0).min() > 10                                                # spread over the range, not constant
+    assert (a[2] >= 0).all() and (a[2] <= 333).all() and (s_[2] == 0).all()            # empty: bounds (0, image_size.min())
+    assert a[2].max() > 250
+    assert torch.equal(a[3, 1:], kp[3, :1].expand(k - 1, 2)) and (s_[3, 1:] == 0).all()  # one point: min == max
+    b2, _ = run(3)
+    c2, _ = run(4)
+    assert torch.equal(a, b2) and not torch.equal(a, c2)
