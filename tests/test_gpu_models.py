@@ -631,3 +631,26 @@ def test_large_2048_properties():
     heat, _ = ext._runner.dense(ext._packed, v0.to(DEV))
     once = ext._runner.nms(heat, 3, 0)
     assert torch.equal(ext._runner.nms(once, 3, 0), once)
+
+
+def test_c4_pair_1024x1024_k2048_vs_oracle():
+    """BASELINE config 4's shape (1024 x 1024 images, 2048 key points; one pair): HIP path vs the CPU oracle -- key-point
+    sets, matched coordinate pairs, scores.  (test_large_2048_properties above covers the same shape by properties.)"""
+    v0, v1 = synthetic.synthetic_pairs(1, 1024, 1024, seed=77)
+    k = 2048
+    pipe = TwoViewPipeline({"extractor": {**PIPE_CONF["extractor"], "max_num_keypoints": k},
+                            "matcher": PIPE_CONF["matcher"]}).eval().to(DEV)
+    size = torch.tensor([[1024.0, 1024.0]])
+    pred = pipe({"view0": {"image": v0.to(DEV), "image_size": size.to(DEV)},
+                 "view1": {"image": v1.to(DEV), "image_size": size.to(DEV)}})
+    sd = weights.superpoint_open_state_dict(0)
+    o = osp.extract(sd, torch.cat([v0, v1], 0), "open", nms_radius=3, max_num_keypoints=k, detection_threshold=0.0)
+    okp, osc, ode = torch.stack(o["keypoints"]), torch.stack(o["keypoint_scores"]), torch.stack(o["descriptors"])
+    for i in range(2):
+        compare_keypoints(f"c4_view{i}", pred[f"keypoints{i}"][0], pred[f"keypoint_scores{i}"][0],
+                          pred[f"descriptors{i}"][0], okp[i], osc[i], ode[i], radius=3)
+    ref = olg.match(weights.lightglue_state_dict(0), okp[:1], okp[1:], ode[:1], ode[1:], size, size, filter_threshold=0.1)
+    mine = match_pairs(pred["keypoints0"][0], pred["keypoints1"][0], pred["matches0"][0])
+    theirs = match_pairs(okp[0], okp[1], ref["matches0"][0])
+    assert len(theirs) > 1000 and len(mine ^ theirs) <= 2, (len(mine), len(theirs), len(mine ^ theirs))
+    record("c4_pair_vs_oracle", ref_matches=len(theirs), identical=len(mine & theirs))
