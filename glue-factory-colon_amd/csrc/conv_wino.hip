@@ -241,6 +241,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   for (int c = 0; c < nchunks; ++c) {
     const bool has_next = c + 1 < nchunks;
     const float* ps = in_s + (c & 1) * WPATCH;
+#if WINO_DIAG & 128  // diagnostic: request the next patch at the top of the chunk instead of after group 0
+    if constexpr (!STEM) {
+      if (has_next) { WINO_LOAD_IN(xin, c + 1); }
+      else if (more) { WINO_GOFS(ny0, nx0); WINO_LOAD_IN(nxin, 0); }
+    }
+#endif
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       const float* p1 = ps + (g ? (o1 ^ 8) : o1);
@@ -285,8 +291,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         if constexpr (STEM) {
           if (has_next) { WINO_FILL_IN(c + 1); }  // VALU work under the MFMAs of this chunk
         } else {
+#if !(WINO_DIAG & 128)
           if (has_next) { WINO_LOAD_IN(xin, c + 1); }
           else if (more) { WINO_GOFS(ny0, nx0); WINO_LOAD_IN(nxin, 0); }
+#endif
         }
       }
     }

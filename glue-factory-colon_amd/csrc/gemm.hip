@@ -36,10 +36,11 @@ struct GemmArgs {
 // Epilogue shared by the GEMM kernels: bias / BN affine / alpha directly from the accumulator layout, or -- when
 // rotary or residual operands have to be loaded per element -- through a per-wave LDS transpose with float4 traffic.
 // Called after the K loop's final workgroup barrier (smem is free).
-template <int NW, int MT>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][MT], float* smem, float* Y, int m0,
+template <int NW, int MT, int MTN = MT>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[MT][MTN], float* smem, float* Y, int m0,
                                               int n0, int wm, int wn, int lane, int wave) {
-  constexpr int WT = 32 * MT;
+  constexpr int WT = 32 * MTN;   // columns per wave
+  constexpr int WTM = 32 * MT;   // rows per wave
   const int l31 = lane & 31, h = lane >> 5;
   // (workgroup-uniform: column tiles at or beyond rot_cols -- the V third of the fused QKV projection -- carry no
   // rotary and take the direct path as well)
@@ -47,7 +48,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
     // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
     // measured faster than the LDS transpose below when nothing has to be loaded per element
 #pragma unroll
-    for (int nt = 0; nt < MT; ++nt) {
+    for (int nt = 0; nt < MTN; ++nt) {
       const int col = n0 + wn * WT + nt * 32 + l31;
       const bool col_ok = col < g.N;
       const int cc = col_ok ? col : g.N - 1;
@@ -58,7 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WT + mt * 32 + acc_row(r, h);
+          const int row = m0 + wm * WTM + mt * 32 + acc_row(r, h);
           float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 1)
           if (row < g.M && col_ok && v == 12345.678f) Y[(size_t)row * g.ldy + col] = v;  // diagnostic: no stores
@@ -102,7 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int nt = 0; nt < MT; ++nt)
+    for (int nt = 0; nt < MTN; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -110,7 +111,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 #pragma unroll
     for (int i = 0; i < 32 / RPS; ++i) {
       const int lr = er + RPS * i;
-      const int row = m0 + wm * WT + mt * 32 + lr;
+      const int row = m0 + wm * WTM + mt * 32 + lr;
       float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
       if (row >= g.M) continue;
       v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
@@ -151,11 +152,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 //                    4x the workgroups, so that a [2048, 256] GEMM still covers the chip
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
 // underneath the MFMAs of the current one.
-template <int NW, int MT, int BK>
-__global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void gemm_nt_kernel(GemmArgs g) {
+template <int NW, int MT, int BK, int MTN = MT>
+__global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ? 4 : 3) : 2)) void gemm_nt_kernel(GemmArgs g) {
   constexpr int T = 128 * NW;        // threads
   constexpr int GBM = 64 * MT;       // tile height (2 waves)
-  constexpr int BN = 32 * MT * NW;   // tile width
+  constexpr int BN = 32 * MTN * NW;  // tile width
   constexpr int GLD = BK + 4;        // LDS row stride (floats)
   constexpr int C4 = BK / 4;         // float4 per staged row
   constexpr int RPP = T / C4;        // rows staged per pass
@@ -230,17 +231,16 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
     }                                                                                                \
   } while (0)
 
-  f32x16 acc[MT][MT];
+  f32x16 acc[MT][MTN];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < MT; ++nt)
+    for (int nt = 0; nt < MTN; ++nt)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-  constexpr int WT = 32 * MT;  // rows / columns per wave
-  const int a_off = (wm * WT + l31) * GLD + 4 * h;
-  const int b_off = GBM * GLD + (wn * WT + l31) * GLD + 4 * h;
+  const int a_off = (wm * 32 * MT + l31) * GLD + 4 * h;
+  const int b_off = GBM * GLD + (wn * 32 * MTN + l31) * GLD + 4 * h;
 
   // Staging order ("write after the barrier"): at the top of K step kt the registers hold tile kt+1 (requested one
   // whole step earlier); they go to the other LDS buffer first, then tile kt+2 is requested, then the MFMAs of tile kt
@@ -259,16 +259,15 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
     const float* bp = smem + (kt & 1) * TILE + b_off;
 #pragma unroll
     for (int gk = 0; gk < BK / 8; ++gk) {
-      float4 af[MT], bf[MT];
+      float4 af[MT], bf[MTN];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * GLD + 8 * gk);
-        bf[mt] = *reinterpret_cast<const float4*>(bp + mt * 32 * GLD + 8 * gk);
-      }
+      for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * GLD + 8 * gk);
+#pragma unroll
+      for (int nt = 0; nt < MTN; ++nt) bf[nt] = *reinterpret_cast<const float4*>(bp + nt * 32 * GLD + 8 * gk);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < MT; ++nt) {
+        for (int nt = 0; nt < MTN; ++nt) {
           acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
           acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
           acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
@@ -278,7 +277,7 @@ __global__ __launch_bounds__(128 * NW, BK == 16 ? (NW == 4 ? 4 : 3) : 2) void ge
     __syncthreads();
   }
 
-  gemm_epilogue<NW, MT>(g, acc, smem, Y, m0, n0, wm, wn, lane, wave);
+  gemm_epilogue<NW, MT, MTN>(g, acc, smem, Y, m0, n0, wm, wn, lane, wave);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -817,16 +816,16 @@ extern "C" int gfc_linear_split(const float* A0, int lda0, int K0, const float* 
   return GFC_OK;
 }
 
-template <int NW, int MT, int BK>
+template <int NW, int MT, int BK, int MTN = MT>
 static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
-  constexpr int BM = 64 * MT, BN = 32 * MT * NW;
+  constexpr int BM = 64 * MT, BN = 32 * MTN * NW;
   // K-loop buffers, or the per-wave transpose patches of the rotary / residual epilogue if those are larger
-  constexpr size_t kloop = (size_t)2 * (BM + BN) * (BK + 4), patches = (size_t)2 * NW * 32 * (32 * MT + 4);
+  constexpr size_t kloop = (size_t)2 * (BM + BN) * (BK + 4), patches = (size_t)2 * NW * 32 * (32 * MTN + 4);
   const size_t lds = (kloop > patches ? kloop : patches) * sizeof(float);
   static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
-  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_nt_kernel<NW, MT, BK>, lds, lds_ok);
+  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_nt_kernel<NW, MT, BK, MTN>, lds, lds_ok);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK>), grid, dim3(128 * NW), lds, st, g);
+  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK, MTN>), grid, dim3(128 * NW), lds, st, g);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
@@ -848,6 +847,7 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 41 KB LDS: 3 workgroups / CU
   if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
   if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);
+  if (choice == 8) return launch_gemm_t<2, 4, 16, 2>(g, batch, st);  // 256x128: 8 accumulator tiles per wave, 2 workgroups / CU
   if (choice == 7) return launch_gemm_dma(g, batch, st);          // 128x128, LDS-DMA staging, 4 workgroups / CU  // 128x256, 61 KB LDS: 2 workgroups of 8 waves / CU
   return launch_gemm_t<2, 1, 32>(g, batch, st);
 }

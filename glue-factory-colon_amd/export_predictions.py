@@ -3,8 +3,9 @@
 `for data in loader: pred = model(data)`; key filtering (`keys` / `optional_keys`, ValueError on a missing
 key), un-scaling of key points to the original image resolution (`keypoints{i} * 1/view{i}.scales`), one record
 per pair named `data["name"][0]` holding every exported key without its batch dimension.  The reference writes
-HDF5 groups through h5py; h5py is used here too when it is importable, otherwise the same records go into
-one `.npz` archive with keys `"<name>/<key>"` (`load_predictions` reads both).
+HDF5 groups through h5py; an `.h5` output here is the same HDF5 layout, written through h5py when it is importable and
+otherwise through the HDF5 C library itself (`_hdf5.py`, ctypes); other suffixes give one `.npz` archive with keys
+`"<name>/<key>"` (`load_predictions` reads both).
 
 MI355X addition (`workers` > 1): the evaluation loop runs at batch 1 (image sizes differ), whose kernels fill only
 part of the chip (conv4 at 60x80: 40 workgroups for 256 CUs).  `workers` host threads, each with its own HIP stream
@@ -192,30 +193,41 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
 
 
 def _write(path: Path, records: dict):
-    try:
-        import h5py
-    except ImportError:
-        h5py = None
-    if h5py is not None and path.suffix in (".h5", ".hdf5"):
-        with h5py.File(str(path), "w") as f:
-            for name, rec in records.items():
-                grp = f.create_group(name)
-                for k, v in rec.items():
-                    grp.create_dataset(k, data=v)
-        return
+    """`.h5` / `.hdf5`: the reference's HDF5 layout (group per record name, dataset per key) through h5py when it is
+    importable, else through the HDF5 C library bound in `_hdf5.py`; any other suffix (or no HDF5 library at all):
+    one `.npz` archive with keys "<name>/<key>"."""
+    if path.suffix in (".h5", ".hdf5"):
+        try:
+            import h5py
+        except ImportError:
+            h5py = None
+        if h5py is not None:
+            with h5py.File(str(path), "w") as f:
+                for name, rec in records.items():
+                    grp = f.create_group(name)
+                    for k, v in rec.items():
+                        grp.create_dataset(k, data=v)
+            return
+        from . import _hdf5
+        if _hdf5.available():
+            _hdf5.write_records(path, records)
+            return
     flat = {f"{name}/{k}": v for name, rec in records.items() for k, v in rec.items()}
     with open(path, "wb") as fh:
         np.savez(fh, **flat)
 
 
 def load_predictions(path):
-    """{name: {key: ndarray}} from either container."""
+    """{name: {key: ndarray}} from either container (HDF5: names in alphabetical order, as HDF5 iterates them)."""
     path = Path(path)
     with open(path, "rb") as fh:
         magic = fh.read(4)
     if magic == b"\x89HDF":
-        import h5py
-
+        try:
+            import h5py
+        except ImportError:
+            from . import _hdf5
+            return _hdf5.read_records(path)
         with h5py.File(str(path), "r") as f:
             out = {}
 

@@ -32,8 +32,12 @@ def pairs_of(kp0, kp1, m0, s0):
             for a in np.nonzero(m0 >= 0)[0].tolist()}
 
 
-@pytest.mark.parametrize("workers", [1, 2])
-def test_c3_official_pipeline_export_golden(golden, tmp_path, workers):
+@pytest.mark.parametrize("workers,container", [(1, "npz"), (2, "npz"), (1, "h5")])
+def test_c3_official_pipeline_export_golden(golden, tmp_path, workers, container):
+    from glue_factory_colon_amd import _hdf5
+
+    if container == "h5" and not _hdf5.available():
+        pytest.skip("no HDF5 C library on this box")
     g = golden("pipeline_official")
     pipe = TwoViewPipeline({
         "extractor": {"name": "gluefactory_nonfree.superpoint", "weights": "synthetic", "max_num_keypoints": 1024,
@@ -42,10 +46,14 @@ def test_c3_official_pipeline_export_golden(golden, tmp_path, workers):
                     "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1}}).eval()
     assert pipe.is_initialized()
     loader = [{"name": [name], **c3_pair(seed, s0, s1, origs)} for name, seed, s0, s1, origs in C3_PAIRS]
-    out = export_predictions(loader, pipe, tmp_path / "predictions.npz", keys=EXPORT_KEYS, optional_keys=OPTIONAL_KEYS,
-                             workers=workers)
+    out = export_predictions(loader, pipe, tmp_path / f"predictions.{container}", keys=EXPORT_KEYS,
+                             optional_keys=OPTIONAL_KEYS, workers=workers)
     recs = load_predictions(out)
-    assert list(recs) == [n for n, *_ in C3_PAIRS] == g["names"].tolist()
+    if container == "h5":  # the reference's own container (predictions.h5): HDF5 iterates names alphabetically
+        assert open(out, "rb").read(4) == b"\x89HDF"
+        assert sorted(recs) == sorted(n for n, *_ in C3_PAIRS)
+    else:
+        assert list(recs) == [n for n, *_ in C3_PAIRS] == g["names"].tolist()
     total = same = 0
     for i, (name, *_rest) in enumerate(C3_PAIRS):
         r = recs[name]
@@ -72,4 +80,4 @@ def test_c3_official_pipeline_export_golden(golden, tmp_path, workers):
         assert (m1[m0[ok]] == np.nonzero(ok)[0]).all()
         total += len(pr)
         same += len(set(pm) & set(pr))
-    record(f"c3_official_pipeline_workers{workers}", ref_matches=total, identical=same)
+    record(f"c3_official_pipeline_workers{workers}_{container}", ref_matches=total, identical=same)

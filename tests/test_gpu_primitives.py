@@ -448,7 +448,7 @@ def test_gemm_tile_variants_via_knob():
     import sys
 
     # 4 = gemm_nt_kernel<2,2,16>, the variant large batches (bench.py: 32 pairs) dispatch to by default
-    for tile in (1, 2, 3, 4, 5, 6, 7):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
         env = dict(os.environ, GFC_GEMM_TILE=str(tile))
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
                             "-k", "linear_plain or linear_concat or linear_rotary or batched_nt", "-p", "no:cacheprovider"],

@@ -6,6 +6,7 @@ import re
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 import torch
 
@@ -318,3 +319,45 @@ def test_export_predictions_sharded_world2_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0 and "SHARDED_EXPORT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_hdf5_prediction_file_without_h5py(tmp_path):
+    """`predictions.h5` in the reference's layout (utils/export_predictions.py:81-90: group per "<seq>/<idx>.ppm",
+    dataset per key) written and read through the HDF5 C library bound by ctypes (h5py is not installed here);
+    export -> CacheLoader round trip on that container."""
+    from glue_factory_colon_amd import _hdf5, cache_loader
+    from glue_factory_colon_amd.export_predictions import export_predictions, load_predictions
+
+    if not _hdf5.available():
+        pytest.skip("no HDF5 C library in this environment")
+    g = torch.Generator().manual_seed(0)
+    recs = {"v_a/2.ppm": {"keypoints0": torch.rand((7, 2), generator=g).numpy(), "matches0": np.arange(7, dtype=np.int64) - 1,
+                          "scores_half": torch.rand((7,), generator=g).numpy().astype(np.float16),
+                          "flag": np.array([True, False, True]), "empty": np.zeros((0, 2), np.float32),
+                          "scalar": np.float32(2.5)},
+            "v_a/3.ppm": {"keypoints0": np.zeros((0, 2), np.float32)},
+            "i_b/6.ppm": {"d": np.arange(12, dtype=np.float64).reshape(3, 4), "u": np.arange(5, dtype=np.int32)}}
+    path = tmp_path / "predictions.h5"
+    _hdf5.write_records(path, recs)
+    assert open(path, "rb").read(8) == b"\x89HDF\r\n\x1a\n"  # a real HDF5 file
+    back = load_predictions(path)
+    assert set(back) == set(recs)
+    for n, rec in recs.items():
+        assert set(back[n]) == set(rec)
+        for k, v in rec.items():
+            v = np.asarray(v)
+            exp = v.astype(np.uint8) if v.dtype == np.bool_ else v
+            assert back[n][k].dtype == exp.dtype and back[n][k].shape == exp.shape and np.array_equal(back[n][k], exp), (n, k)
+
+    class Fake(torch.nn.Module):
+        def forward(self, data):
+            return {"keypoints": data["x"] * 3, "keypoint_scores": data["x"][..., 0], "descriptors": data["x"].repeat(1, 1, 4)}
+
+    items = [{"name": [f"s/{i}.ppm"], "x": torch.rand((1, 5, 2), generator=g), "scales": torch.tensor([[0.5, 2.0]])}
+             for i in range(3)]
+    out = export_predictions(items, Fake(), tmp_path / "feats.h5", keys=["keypoints", "keypoint_scores", "descriptors"])
+    assert open(out, "rb").read(4) == b"\x89HDF"
+    loader = cache_loader.CacheLoader({"path": str(out), "add_data_path": False}).eval()
+    got = loader({"name": [items[1]["name"][0]], "scales": items[1]["scales"]})
+    assert torch.allclose(got["keypoints"][0], items[1]["x"][0] * 3)  # un-scaled on export, re-scaled on load
+    assert torch.equal(got["keypoint_scores"][0], items[1]["x"][0, :, 0])
