@@ -1,0 +1,111 @@
+"""Randomised shape sweep of gfc_conv3x3_wino / gfc_lg_assign / gfc_disk_nms_select against torch float64 / the oracle
+(run on the GPU box: python tools/micro/fuzz_shapes.py [n_cases]).  Prints the worst error and any failing shape."""
+import ctypes
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from glue_factory_colon_amd import _native as nat  # noqa: E402
+from oracle import disk as odisk  # noqa: E402
+from oracle import lightglue as olg  # noqa: E402
+
+def run(n_cases=60, seed=2024):
+    """-> list of failing cases (empty when every shape agrees)."""
+    lib = nat.lib()
+    DEV = torch.device("cuda", 0)
+    st = nat.stream_ptr(DEV)
+    g = torch.Generator().manual_seed(seed)
+
+    def ri(lo, hi):
+        return int(torch.randint(lo, hi + 1, (1,), generator=g))
+
+    worst, bad = 0.0, []
+    for case in range(n_cases):
+        cin, cout = [16, 32, 64, 128][ri(0, 3)], [64, 128][ri(0, 1)]
+        h, w, b, pool = ri(1, 70), ri(1, 70), ri(1, 3), ri(0, 1)
+        if pool and (h < 2 or w < 2):
+            continue
+        x = torch.randn((b, cin, h, w), generator=g)
+        wt = torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)
+        bias = torch.randn((cout,), generator=g) * 0.1
+        ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1))
+        if pool:
+            ref = F.max_pool2d(ref, 2, 2)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        wd, bd = wt.to(DEV), bias.to(DEV)
+        ww = torch.empty((16 * cout * cin,), device=DEV)
+        nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(wd), nat.ptr(ww), cout, cin, st), "pack")
+        ho, wo = (h // 2, w // 2) if pool else (h, w)
+        y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
+        nat.check(lib.gfc_conv3x3_wino(nat.ptr(xd), nat.ptr(ww), nat.ptr(bd), None, None, nat.ptr(y), b, h, w, cin, cout, 1,
+                                       pool, st), "wino")
+        torch.cuda.synchronize()
+        err = (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() if ref.numel() else 0.0
+        worst = max(worst, err)
+        if not err < 2e-5:
+            bad.append(("wino", cin, cout, h, w, b, pool, err))
+    print("winograd: worst", worst, "bad", bad)
+    failures = list(bad)
+
+    bad = []
+    for case in range(n_cases):
+        h, w, b = ri(1, 90), ri(1, 90), ri(1, 3)
+        n = [None, ri(1, 50), ri(50, 4000)][ri(0, 2)]
+        window = [1, 3, 5, 7, 9][ri(0, 4)]
+        heat = torch.randn((b, 1, h, w), generator=g)
+        if ri(0, 1):
+            heat = (heat * 3).round() / 3
+        ref = odisk.heatmap_to_keypoints(heat, n, window, 0.0)
+        cap = n if n is not None else h * w
+        kp = torch.full((b, cap, 2), -7.0, device=DEV)
+        sc = torch.full((b, cap), -7.0, device=DEV)
+        cnt = torch.empty((b,), dtype=torch.int32, device=DEV)
+        ws = torch.empty(lib.gfc_disk_select_workspace_bytes(b, h, w), dtype=torch.uint8, device=DEV)
+        hd = heat.reshape(b, h, w).contiguous().to(DEV)
+        nat.check(lib.gfc_disk_nms_select(nat.ptr(hd), b, h, w, window, 0.0, -1 if n is None else n, cap, nat.ptr(kp), nat.ptr(sc),
+                                          nat.ptr(cnt), nat.ptr(ws), ws.numel(), st), "disk")
+        torch.cuda.synchronize()
+        for i, (xy, s) in enumerate(ref):
+            c = int(cnt[i])
+            if c != xy.shape[0] or not torch.equal(kp[i, :c].cpu(), xy.float()) or not torch.equal(sc[i, :c].cpu(), s):
+                bad.append(("disk", h, w, b, n, window, i, c, xy.shape[0]))
+    print("disk select: bad", bad)
+    failures += bad
+
+    bad, worst = [], 0.0
+    for case in range(max(n_cases // 3, 8)):
+        b, m, n = ri(1, 3), ri(1, 1300), ri(1, 1300)
+        x0, x1 = torch.randn((b, m, 256), generator=g), torch.randn((b, n, 256), generator=g)
+        sd = {"log_assignment.0.final_proj.weight": torch.randn((256, 256), generator=g) / 8,
+              "log_assignment.0.final_proj.bias": torch.randn((256,), generator=g) * 0.1,
+              "log_assignment.0.matchability.weight": torch.randn((1, 256), generator=g) / 16,
+              "log_assignment.0.matchability.bias": torch.randn((1,), generator=g)}
+        ref = olg.match_assignment(sd, "log_assignment.0", x0, x1)
+        r0, r1, _, _ = olg.filter_matches(ref, 0.1)
+        keep = [sd[k].to(DEV).contiguous() for k in sd]
+        p = nat.LgParams()
+        p.n_layers, p.input_dim = 1, 256
+        p.final_proj_w[0], p.final_proj_b[0] = keep[0].data_ptr(), keep[1].data_ptr()
+        p.matchability_w[0], p.matchability_b[0] = keep[2].reshape(-1).data_ptr(), keep[3].data_ptr()
+        m0 = torch.empty((b, m), dtype=torch.long, device=DEV)
+        m1 = torch.empty((b, n), dtype=torch.long, device=DEV)
+        s0, s1 = torch.empty((b, m), device=DEV), torch.empty((b, n), device=DEV)
+        la = torch.full((b, m + 1, n + 1), float("nan"), device=DEV)
+        ws = torch.full((lib.gfc_lg_assign_workspace_bytes(b, m, n),), 0xFF, dtype=torch.uint8, device=DEV)
+        x0d, x1d = x0.reshape(b * m, 256).to(DEV), x1.reshape(b * n, 256).to(DEV)
+        nat.check(lib.gfc_lg_assign(ctypes.byref(p), 0, nat.ptr(x0d), nat.ptr(x1d), b, m, n, 0.1, nat.ptr(m0), nat.ptr(m1),
+                                    nat.ptr(s0), nat.ptr(s1), nat.ptr(la), nat.ptr(ws), ws.numel(), st), "assign")
+        torch.cuda.synchronize()
+        err = ((la.cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        worst = max(worst, err)
+        if not (err < 1e-4 and torch.equal(m0.cpu(), r0) and torch.equal(m1.cpu(), r1)):
+            bad.append(("assign", b, m, n, err, int((m0.cpu() != r0).sum()), int((m1.cpu() != r1).sum())))
+    print("assign: worst", worst, "bad", bad)
+    return failures + bad
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60) else 0)
