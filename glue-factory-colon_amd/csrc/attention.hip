@@ -32,21 +32,32 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
                                                            const float* __restrict__ V, int ldv,
                                                            float* __restrict__ O, int ldo,
                                                            const int4* __restrict__ problems, float scale_log2e,
-                                                           int ksplit, float* __restrict__ part, int max_nq) {
+                                                           int ksplit, float* __restrict__ part, int max_nq, int xcd_remap) {
   // double-buffered K / V tiles: [2][AK*AKLD] keys, then [2][AK*AD] values (67.6 KB -> 2 workgroups / CU)
   __shared__ __attribute__((aligned(16))) float smem[2 * AK * AKLD + 2 * AK * AD];
   constexpr int AQ = 32 * AW * QT;
   constexpr int T = 64 * AW;
   constexpr int NLD = (AK * AD / 4) / T;  // float4 of K (and of V) per thread per tile
 
-  const int4 pb = problems[blockIdx.z];
+  // XCD-aware order (common.h): the query blocks (and key splits) of one (problem, head) run at the same time behind
+  // one L2, so its K and V rows come from HBM once instead of once per query block
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (xcd_remap) {
+    const unsigned per_z = gridDim.x * gridDim.y;
+    unsigned t = gfc_xcd_chunk(bx + gridDim.x * (by + gridDim.y * bz), per_z * gridDim.z);
+    bz = t / per_z;
+    t -= bz * per_z;
+    by = t / gridDim.x;
+    bx = t - by * gridDim.x;
+  }
+  const int4 pb = problems[bz];
   const int q_row0 = pb.x, nq = pb.y, kv_row0 = pb.z, nk = pb.w;
-  // key split (small problems only): blockIdx.x = q-block * ksplit + s; split s walks its share of the key
+  // key split (small problems only): bx = q-block * ksplit + s; split s walks its share of the key
   // tiles and leaves an un-normalised partial (O, m, l) for attention_merge_kernel
-  const int ks = blockIdx.x % ksplit;
-  const int qt0 = (blockIdx.x / ksplit) * AQ;
+  const int ks = bx % ksplit;
+  const int qt0 = (bx / ksplit) * AQ;
   if (qt0 >= nq) return;  // uniform for the whole workgroup
-  const int head = blockIdx.y;
+  const int head = by;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
 
@@ -202,7 +213,7 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
       if (q[t] < nq) {
-        float* pp = part + ((((size_t)blockIdx.z * gridDim.y + head) * max_nq + q[t]) * ksplit + ks) * 66;
+        float* pp = part + ((((size_t)bz * gridDim.y + head) * max_nq + q[t]) * ksplit + ks) * 66;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -280,6 +291,7 @@ extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, c
   // key split for small problem sets (batch 1..2): few 128-query blocks cannot fill 1024 SIMDs, so each block's
   // keys are shared out over up to 8 workgroups and a tiny merge kernel combines the partial soft-maxes
   const int forced_split = gfc_knobs().attn_split;
+  const int xcd = gfc_knobs().xcd_remap != 0;
   int ksplit = 1;
   if (cfg == 2 && ws != nullptr) {
     const long long w = wgs(128);
@@ -290,17 +302,17 @@ extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, c
   }
   if (cfg == 1) {
     hipLaunchKernelGGL((attention_kernel<2, 4>), dim3((max_nq + 255) / 256, heads, n_problems), dim3(256), 0, st, Q,
-                       ldq, K, ldk, V, ldv, O, ldo, pt, sl2, 1, (float*)nullptr, max_nq);
+                       ldq, K, ldk, V, ldv, O, ldo, pt, sl2, 1, (float*)nullptr, max_nq, xcd);
   } else if (cfg == 2) {
     float* part = ksplit > 1 ? (float*)ws : nullptr;
     hipLaunchKernelGGL((attention_kernel<1, 4>), dim3(((max_nq + 127) / 128) * ksplit, heads, n_problems), dim3(256), 0,
-                       st, Q, ldq, K, ldk, V, ldv, O, ldo, pt, sl2, ksplit, part, max_nq);
+                       st, Q, ldq, K, ldk, V, ldv, O, ldo, pt, sl2, ksplit, part, max_nq, xcd);
     if (ksplit > 1)
       hipLaunchKernelGGL(attention_merge_kernel, dim3((max_nq + 3) / 4, heads, n_problems), dim3(256), 0, st, part, O,
                          ldo, pt, ksplit, max_nq, sl2);
   } else {
     hipLaunchKernelGGL((attention_kernel<1, 2>), dim3((max_nq + 63) / 64, heads, n_problems), dim3(128), 0, st, Q, ldq,
-                       K, ldk, V, ldv, O, ldo, pt, sl2, 1, (float*)nullptr, max_nq);
+                       K, ldk, V, ldv, O, ldo, pt, sl2, 1, (float*)nullptr, max_nq, xcd);
   }
   GFC_LAUNCH_CHECK();
   return GFC_OK;

@@ -30,6 +30,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// XCD-aware work order.  Workgroups whose flat dispatch ids agree modulo 8 run on the same XCD, i.e. behind the same
+// 4 MB L2 (observed placement, MI355X_MICROARCH.md: a label, used for speed only -- results never depend on it).
+// gfc_xcd_chunk maps flat id -> logical index such that each XCD walks ONE contiguous chunk of the logical index space
+// in dispatch order: workgroups that share operands (the column tiles of a GEMM row panel, the query blocks of an
+// attention head, the output-channel blocks and neighbours of a convolution tile) then hit the L2 that already holds
+// them.  Bijective on [0, n) for every n.
+__device__ __forceinline__ unsigned gfc_xcd_chunk(unsigned id, unsigned n) {
+  const unsigned q = n >> 3, r = n & 7, x = id & 7;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+}
+
 #define GFC_LAUNCH_CHECK()                                   \
   do {                                                       \
     if (hipGetLastError() != hipSuccess) return GFC_ERR_LAUNCH; \

@@ -53,6 +53,7 @@ struct WinoArgs {
   const float* b1;
   const float* s1;
   const float* t1;
+  int xcd_remap;  // walk the work items in XCD-contiguous order (runtime.h: GFC_XCD_REMAP)
 };
 
 // U = G g G^T in float64, rounded once; scattered into MFMA-fragment order:
@@ -106,20 +107,29 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int l31 = lane & 31, h = lane >> 5;                 // (filter stream base, transform rows) stays in SGPRs
   const int cin = a.cin, nchunks = cin / WKC;
 
-  // Persistent workgroups: work item = tile + ntiles * (output-channel block); a workgroup walks the items
-  // blockIdx.x, blockIdx.x + gridDim.x, ...  The first input patch, the first filter fragments (and, in the stem, the
+  // Persistent workgroups: a workgroup walks the work items blockIdx.x, blockIdx.x + gridDim.x, ...  Item order
+  // (XCD-aware, common.h: gfc_xcd_chunk -- gridDim.x is a multiple of 8 whenever the loop runs more than once): each
+  // XCD owns a contiguous run of items = whole images; inside the run a PAIR of output-channel blocks is the fastest
+  // index, then the tile column, the tile row, the image and last the remaining output-channel blocks -- the two
+  // channel blocks of a tile and its neighbours' halos are read while the tile's input is still in that XCD's L2
+  // (all blocks fastest would put cout/64 x 0.5 MB of filters into the L2 working set of the 512-channel head layer).
+  // The first input patch, the first filter fragments (and, in the stem, the
   // image patch) of the NEXT item are requested during the last chunk of the current one and land under its epilogue.
   // Exit: the item index is a pure function of blockIdx / gridDim (no queue, no inter-workgroup dependency).
   const int ntiles = a.tiles_x * a.tiles_y * a.B;
   const int nitems = ntiles * (a.cout / 64);
+  const int nbpair = (a.cout / 64) % 2 == 0 ? 2 : 1;
   int item = blockIdx.x;
   int x0, y0, b, nb;
   const float* xin;
   const float4* wp;  // B stream: fragments of this wave's four positions, contiguous per k group (8 x 64 float4)
 #define WINO_DECODE(w_, x0_, y0_, b_, nb_, xin_, wp_)                                              \
   do {                                                                                             \
-    int t_ = (w_) % ntiles;                                                                        \
-    nb_ = (w_) / ntiles;                                                                           \
+    unsigned l_ = a.xcd_remap ? gfc_xcd_chunk((unsigned)(w_), (unsigned)nitems) : (unsigned)(w_);  \
+    const int lo_ = (int)(l_ % (unsigned)nbpair);                                                  \
+    l_ /= (unsigned)nbpair;                                                                        \
+    int t_ = (int)(l_ % (unsigned)ntiles);                                                         \
+    nb_ = (int)(l_ / (unsigned)ntiles) * nbpair + lo_;                                             \
     x0_ = (t_ % a.tiles_x) * WT_X;                                                                 \
     t_ /= a.tiles_x;                                                                               \
     y0_ = (t_ % a.tiles_y) * WT_Y;                                                                 \
@@ -385,10 +395,13 @@ static int launch_wino(const WinoArgs& a, hipStream_t st) {
   static std::atomic<unsigned long long> lds_ok{0};
   if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)conv3x3_wino_kernel<POOL, STEM>, lds, lds_ok);
   const long long nitems = (long long)a.tiles_x * a.tiles_y * a.B * (a.cout / 64);
-  const long long resident = (long long)gfc_device_cus() * 2;  // two workgroups per CU (registers, 64-68 KB LDS)
+  long long resident = ((long long)gfc_device_cus() * 2) & ~7ll;  // two workgroups per CU (registers, 64-68 KB LDS);
+  if (resident < 8) resident = 8;                               // a multiple of 8: the XCD label of an item = item % 8
   const int forced = gfc_knobs().conv_persist;                 // GFC_CONV_PERSIST=0: one workgroup per item
   const long long grid = (STEM || forced == 0 || nitems < resident) ? nitems : resident;
-  hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, STEM>), dim3((unsigned)grid), dim3(256), lds, st, a);
+  WinoArgs wa = a;
+  wa.xcd_remap = gfc_knobs().xcd_remap != 0 && nitems >= 16;
+  hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, STEM>), dim3((unsigned)grid), dim3(256), lds, st, wa);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

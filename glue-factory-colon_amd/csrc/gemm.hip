@@ -31,6 +31,7 @@ struct GemmArgs {
   int lda0, lda1, ldw, ldy;
   int K0, K1, M, N, rot_cols;
   float alpha;
+  int xcd_remap;  // gemm_nt_kernel: walk the tiles in XCD-contiguous order (runtime.h: GFC_XCD_REMAP)
 };
 
 // Epilogue shared by the GEMM kernels: bias / BN affine / alpha directly from the accumulator layout, or -- when
@@ -169,8 +170,19 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ?
   const int lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / NW, wn = wave % NW;
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * BN;
-  const long long z = blockIdx.z;
+  // XCD-aware tile order (column tile fastest): the gridDim.x column tiles of a row panel run at the same time behind
+  // ONE L2, so the panel of A is fetched from HBM once instead of once per column tile
+  unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (g.xcd_remap) {
+    const unsigned per_z = gridDim.x * gridDim.y;
+    unsigned t = gfc_xcd_chunk(bx + gridDim.x * (by + gridDim.y * bz), per_z * gridDim.z);
+    bz = t / per_z;
+    t -= bz * per_z;
+    by = t / gridDim.x;
+    bx = t - by * gridDim.x;
+  }
+  const int m0 = by * GBM, n0 = bx * BN;
+  const long long z = bz;
   const float* A0 = g.A0 + z * g.strideA;
   const float* A1 = g.A1 ? g.A1 + z * g.strideA : nullptr;
   const float* W = g.W + z * g.strideW;
@@ -825,7 +837,9 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
   if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_nt_kernel<NW, MT, BK, MTN>, lds, lds_ok);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
-  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK, MTN>), grid, dim3(128 * NW), lds, st, g);
+  GemmArgs ga = g;
+  ga.xcd_remap = gfc_knobs().xcd_remap != 0 && (long long)grid.x * grid.y * grid.z >= 16;
+  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK, MTN>), grid, dim3(128 * NW), lds, st, ga);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

@@ -105,7 +105,7 @@ template <int RAD>
 __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ heat, int H, int W, int border,
                                                    const int* __restrict__ valid_wh, float* __restrict__ out,
                                                    float cand_thr, unsigned long long* __restrict__ cand,
-                                                   int* __restrict__ cand_count) {
+                                                   int* __restrict__ cand_count, int xcd_remap) {
   constexpr int HALO = 5 * RAD;
   constexpr int R = NT + 2 * HALO;
   constexpr int RS = R | 1;
@@ -120,7 +120,15 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ hea
 
   const int tid = threadIdx.x;
   const int tiles_x = (W + NT - 1) / NT;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, b = blockIdx.y;
+  // XCD-aware order (common.h): an XCD walks whole images tile by tile, the 5r halo a tile shares with its
+  // neighbours is then served by that XCD's L2
+  unsigned tile = blockIdx.x, img = blockIdx.y;
+  if (xcd_remap) {
+    const unsigned t = gfc_xcd_chunk(tile + gridDim.x * img, gridDim.x * gridDim.y);
+    img = t / gridDim.x;
+    tile = t - img * gridDim.x;
+  }
+  const int tx = tile % tiles_x, ty = tile / tiles_x, b = img;
   const int gx0 = tx * NT - HALO, gy0 = ty * NT - HALO;
   const float* hb = heat + (size_t)b * H * W;
   for (int i = tid; i < R * R; i += 1024) {
@@ -230,7 +238,7 @@ static int launch_nms(const float* heat, int B, int H, int W, int border, const 
   if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)nms_kernel<RAD>, lds, lds_ok);
   dim3 grid(((W + NT - 1) / NT) * ((H + NT - 1) / NT), B);
   hipLaunchKernelGGL(nms_kernel<RAD>, grid, dim3(1024), lds, st, heat, H, W, border, valid_wh, out, cand_thr, cand,
-                     cand_count);
+                     cand_count, gfc_knobs().xcd_remap != 0 && (long long)grid.x * grid.y >= 16);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

@@ -256,7 +256,8 @@ def test_conv3x3_split_accuracy(cin, cout, h, w, pool):
 @pytest.mark.parametrize("cin,cout,h,w,pool,bn", [(64, 64, 32, 48, True, True), (64, 128, 30, 40, False, True),
                                                    (128, 128, 17, 23, True, False), (128, 512, 15, 20, False, True),
                                                    (64, 64, 33, 47, True, True), (16, 64, 5, 3, False, False),
-                                                   (128, 128, 60, 80, False, True), (64, 64, 240, 320, True, True)])
+                                                   (128, 128, 60, 80, False, True), (64, 64, 240, 320, True, True),
+                                                   (64, 128, 104, 152, False, True)])  # 780 items: persistent, 780 % 8 != 0
 def test_conv3x3_winograd(cin, cout, h, w, pool, bn):
     """gfc_conv3x3_wino (Winograd F(2x2,3x3), fp32 MFMA, filters transformed in float64 at pack time) against a
     float64 convolution: the error must be of the order of the direct fp32-MFMA kernel's (both ~1e-6 here)."""
@@ -1006,6 +1007,22 @@ def test_assignment_tail_variants_via_knob():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
                         "assignment_head_two_pass", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
                        timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
+
+
+def test_dispatch_order_variants_via_knob():
+    """GFC_XCD_REMAP=0 (work items in plain dispatch order instead of the XCD-contiguous order of common.h:
+    gfc_xcd_chunk) stays selectable; the order is a speed choice only, so the same tests pass -- including the
+    many-item convolution (persistent hand-over, every item visited exactly once), ragged GEMM / attention grids and
+    the bit-exact NMS."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GFC_XCD_REMAP="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "test_conv3x3_winograd or test_stem_winograd or many_items or test_linear_plain or "
+                        "natural_dispatch or test_attention or test_nms_large or test_fused_nms_select",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
 
 
