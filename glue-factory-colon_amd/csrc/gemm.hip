@@ -32,7 +32,21 @@ struct GemmArgs {
   int K0, K1, M, N, rot_cols;
   float alpha;
   int xcd_remap;  // gemm_nt_kernel: walk the tiles in XCD-contiguous order (runtime.h: GFC_XCD_REMAP)
+  int wide_stores;  // every epilogue through the per-wave LDS transpose: float4 stores (runtime.h: GFC_GEMM_EPI)
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  unsigned long long* stamps;  // diagnostic build (tools/micro/gemm_timeline.py): 8 words per wave
+#endif
 };
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+static unsigned long long* g_diag_stamps = nullptr;
+extern "C" void gfc_diag_set_gemm_stamps(void* p) { g_diag_stamps = (unsigned long long*)p; }
+#define GEMM_STAMP(i_)                                                                               \
+  do {                                                                                               \
+    if (g.stamps && lane == 0) stamp_base[i_] = __builtin_readcyclecounter();                        \
+  } while (0)
+#else
+#define GEMM_STAMP(i_) do {} while (0)
+#endif
 
 // Epilogue shared by the GEMM kernels: bias / BN affine / alpha directly from the accumulator layout, or -- when
 // rotary or residual operands have to be loaded per element -- through a per-wave LDS transpose with float4 traffic.
@@ -45,7 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
   const int l31 = lane & 31, h = lane >> 5;
   // (workgroup-uniform: column tiles at or beyond rot_cols -- the V third of the fused QKV projection -- carry no
   // rotary and take the direct path as well)
-  if ((g.rot_cos == nullptr || n0 >= g.rot_cols) && g.residual == nullptr) {
+  if ((g.rot_cos == nullptr || n0 >= g.rot_cols) && g.residual == nullptr && !g.wide_stores) {
     // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
     // measured faster than the LDS transpose below when nothing has to be loaded per element
 #pragma unroll
@@ -188,6 +202,19 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ?
   const float* W = g.W + z * g.strideW;
   float* Y = g.Y + z * g.strideY;
   const int ktiles = (g.K0 + g.K1) / BK;
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  unsigned long long* stamp_base =
+      g.stamps ? g.stamps + ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * (T / 64) + wave) * 8
+               : nullptr;
+  if (g.stamps && lane == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    stamp_base[5] = hw;
+    stamp_base[6] = xcc;
+  }
+  GEMM_STAMP(0);
+#endif
 
   const int s_c4 = (tid % C4) * 4;
   // staged row of this thread.  With a 16-deep K tile a ds_write_b128 lane group (8 consecutive lanes) covers two
@@ -262,6 +289,7 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ?
   GEMM_STORE_TILE(0);
   if (ktiles > 1) GEMM_LOAD_TILE(1);
   __syncthreads();
+  GEMM_STAMP(1);
   for (int kt = 0; kt < ktiles; ++kt) {
     if (kt + 1 < ktiles) {
       GEMM_STORE_TILE((kt + 1) & 1);
@@ -288,8 +316,14 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ?
     }
     __syncthreads();
   }
+  GEMM_STAMP(2);
 
   gemm_epilogue<NW, MT, MTN>(g, acc, smem, Y, m0, n0, wm, wn, lane, wave);
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  GEMM_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GEMM_STAMP(4);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -839,6 +873,11 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
   GemmArgs ga = g;
   ga.xcd_remap = gfc_knobs().xcd_remap != 0 && (long long)grid.x * grid.y * grid.z >= 16;
+  ga.wide_stores = gfc_knobs().gemm_epi == 1 && g.ldy % 4 == 0 && (reinterpret_cast<size_t>(g.Y) & 15) == 0 &&
+                   g.strideY % 4 == 0;
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  ga.stamps = g_diag_stamps;
+#endif
   hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK, MTN>), grid, dim3(128 * NW), lds, st, ga);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
