@@ -54,7 +54,17 @@ struct WinoArgs {
   const float* s1;
   const float* t1;
   int xcd_remap;  // walk the work items in XCD-contiguous order (runtime.h: GFC_XCD_REMAP)
+#if WINO_DIAG & 256
+  unsigned long long* diag;  // diagnostic build (tools/micro/wino_timeline.py): 8 words per wave
+#endif
 };
+#if WINO_DIAG & 256
+static unsigned long long* g_wino_diag = nullptr;
+extern "C" void gfc_diag_set_wino_stamps(void* p) { g_wino_diag = (unsigned long long*)p; }
+#define WINO_T(v_) const unsigned long long v_ = __builtin_readcyclecounter()
+#else
+#define WINO_T(v_) do {} while (0)
+#endif
 
 // U = G g G^T in float64, rounded once; scattered into MFMA-fragment order:
 //   out[nb][xi][kg][nu][nt][lane = 32 h + l31][s]  <-  U[xi][nu] of (cout = 64 nb + 32 nt + l31, cin = 8 kg + 4 h + s)
@@ -229,7 +239,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int o1 = (R1 * WP_C + tx) * WKC + ((h ^ (R1 & 3)) << 2);
   const int o2 = (R2 * WP_C + tx) * WKC + ((h ^ (R2 & 3)) << 2);
 
+#if WINO_DIAG & 256
+  unsigned long long d_k = 0, d_x = 0, d_s = 0, d_n = 0;
+  const unsigned long long d_t0 = __builtin_readcyclecounter();
+#endif
   while (true) {
+  WINO_T(t_a);
   WINO_STORE_IN(0);
   __syncthreads();
   f32x16 acc[4][2];
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
     if (!(WINO_DIAG & 64)) __syncthreads();
   }
 
+  WINO_T(t_b);
   // ---- output transform.  Column direction (nu) lane-local: z0 = M0 + M1 + M2, z1 = M1 - M2 - M3 ----
   // exchange buffer [xi 4][j 2][tile 32][cout 64]: written from the accumulator layout (cout on the lane: 128-byte
   // runs), read back with 4 consecutive channels per lane (ds_read_b128; 16 lanes = the 256 contiguous bytes of one
@@ -327,6 +343,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       ex[(xi * 2 + 1) * 2048 + o] = (m1 - m2) - m3;
     }
   __syncthreads();
+  WINO_T(t_c);
   // row direction (xi) across the waves, then bias / ReLU / BN / pool: thread -> channel quad q of tiles t, t + 16
   const int q4 = (tid & 15) * 4;
   const int co = nb * 64 + q4;
@@ -376,10 +393,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
         }
     }
   }
+#if WINO_DIAG & 256
+  {
+    WINO_T(t_d);
+    d_k += t_b - t_a; d_x += t_c - t_b; d_s += t_d - t_c; d_n += 1;
+  }
+#endif
   if (!more) break;
   item = next_item; x0 = nx0; y0 = ny0; b = nbb; nb = nnb; xin = nxin; wp = nwp;
   __syncthreads();  // the exchange buffer has been read: the next item's first patch may land in LDS
   }  // persistent loop over work items
+#if WINO_DIAG & 256
+  if (a.diag && lane == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long* o = a.diag + ((size_t)blockIdx.x * 4 + xi) * 8;
+    o[0] = d_k; o[1] = d_x; o[2] = d_s; o[3] = d_n; o[4] = __builtin_readcyclecounter() - d_t0; o[5] = hw; o[6] = d_t0;
+  }
+#endif
 #undef WINO_DECODE
 #undef WINO_GOFS
 #undef WINO_LOAD_IN
@@ -401,6 +432,9 @@ static int launch_wino(const WinoArgs& a, hipStream_t st) {
   const long long grid = (STEM || forced == 0 || nitems < resident) ? nitems : resident;
   WinoArgs wa = a;
   wa.xcd_remap = gfc_knobs().xcd_remap != 0 && nitems >= 16;
+#if WINO_DIAG & 256
+  wa.diag = g_wino_diag;
+#endif
   hipLaunchKernelGGL((conv3x3_wino_kernel<POOL, STEM>), dim3((unsigned)grid), dim3(256), lds, st, wa);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
