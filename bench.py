@@ -19,6 +19,7 @@ convolution conv1a+conv1b+pool, timed live with HIP events around each launch in
 `cpu_baseline` (the CPU oracle, a PyTorch-CPU port of the reference path, on a bounded sample).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -430,6 +431,14 @@ def main():
             out["roofline"]["mfma_frac"] = round(mfma_tf / FP32_MFMA_PEAK_TFLOPS, 4)
             out["roofline"]["note"] = ("Winograd F(2x2,3x3) on fp32 MFMA: frac = algorithmic FLOPs / peak may exceed 1; "
                                        "mfma_frac = FLOPs the matrix pipe actually executes / peak")
+        try:  # what the matrix pipe of THIS box sustains (the data-sheet 157.3 TFLOP/s assumes 2.4 GHz): context only
+            tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
+            nat.check(nat.lib().gfc_probe_mfma_peak(80000, ctypes.byref(tf), ctypes.byref(ghz), nat.stream_ptr(dev)), "probe")
+            out["roofline"]["sustained_mfma_probe"] = {
+                "tflops": round(tf.value, 1), "shader_clock_ghz": round(ghz.value, 3),
+                "note": "registers-only v_mfma_f32_32x32x2_f32 loop on every SIMD, measured after the timed region"}
+        except Exception as e:  # noqa: BLE001
+            out["roofline"]["sustained_mfma_probe"] = {"tflops": None, "error": repr(e)[:120]}
         if split_info is not None:
             out["experimental_split_arithmetic"] = split_info
         if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":

@@ -72,6 +72,7 @@ SIGNATURES = {
     "gfc_sp_workspace_bytes": (c_size_t, [c_int] * 4),
     "gfc_sp_dense": (c_int, [POINTER(SpParams), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                              c_size_t, POINTER(Trace), c_void_p]),
+    "gfc_probe_mfma_peak": (c_int, [c_int, POINTER(c_float), POINTER(c_float), c_void_p]),
     "gfc_event_create": (c_int, [POINTER(c_void_p)]),
     "gfc_event_destroy": (c_int, [c_void_p]),
     "gfc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),

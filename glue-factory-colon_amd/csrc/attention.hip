@@ -22,6 +22,17 @@
 #define AD 64    // head dim
 #define AKLD (AD + 4)
 
+#ifdef ATT_DIAG  // diagnostic build (tools/micro/attn_timeline.py): per-wave cycle accounting, 8 words per wave
+__device__ unsigned long long* g_att_diag_dev = nullptr;
+extern "C" void gfc_diag_set_attn_stamps(void* p) {
+  unsigned long long* q = (unsigned long long*)p;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_att_diag_dev), &q, sizeof(q));
+}
+#define ATT_T(v_) const unsigned long long v_ = __builtin_readcyclecounter()
+#else
+#define ATT_T(v_) do {} while (0)
+#endif
+
 // QT = 32-query tiles per wave (1 or 2): a workgroup covers 128*QT queries.  With QT = 2 every K / V
 // fragment read from LDS feeds two independent score tiles, the barrier count per query halves, and
 // the MFMAs of one tile can issue while the softmax of the other runs on the VALU.
@@ -60,6 +71,10 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
   const int head = by;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
+#ifdef ATT_DIAG
+  unsigned long long d_bar = 0, d_store = 0;
+#endif
+  ATT_T(t_entry);
 
   // ---- Q fragments: lane (q, h) keeps Q[q][8g + 4h + s], g = 0..7, s = 0..3 ----
   int q[QT];
@@ -131,6 +146,7 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
     ATT_STORE(0);
   }
   __syncthreads();
+  ATT_T(t_loop);
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool has_next = kt + 1 < kt1;
     if (has_next) ATT_LOAD(kt + 1);
@@ -204,9 +220,23 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
         }
       }
     }
+#ifdef ATT_DIAG
+    {
+      ATT_T(t_s0);
+      if (has_next) ATT_STORE(buf ^ 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      ATT_T(t_s1);
+      __syncthreads();
+      ATT_T(t_s2);
+      d_store += t_s1 - t_s0;
+      d_bar += t_s2 - t_s1;
+    }
+#else
     if (has_next) ATT_STORE(buf ^ 1);
     __syncthreads();
+#endif
   }
+  ATT_T(t_end);
 
   // ---- key-split partials: [problem][head][q][split][64 O | m | l] ----
   if (part != nullptr) {
@@ -243,6 +273,16 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
         }
     }
   }
+#ifdef ATT_DIAG
+  if (g_att_diag_dev && lane == 0) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long* dd = g_att_diag_dev +
+        ((size_t)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * AW + wave) * 8;
+    dd[0] = t_loop - t_entry; dd[1] = t_end - t_loop; dd[2] = d_bar; dd[3] = d_store;
+    dd[4] = __builtin_readcyclecounter() - t_end; dd[5] = hw; dd[6] = t_entry;
+  }
+#endif
 }
 
 // combine the key-split partials: one wave per (query, head); lane = channel

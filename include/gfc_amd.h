@@ -183,6 +183,12 @@ int gfc_event_destroy(void* event);
 /* milliseconds between two recorded events (both must have completed) */
 int gfc_event_elapsed_ms(void* start, void* stop, float* ms);
 
+/* bench-only: what the matrix pipe of THIS device sustains.  Every SIMD of every CU issues `mfmas_per_wave`
+ * back-to-back v_mfma_f32_32x32x2_f32 (registers only, 4 accumulators); returns the fp32-MFMA rate over the whole
+ * launch and the shader clock it ran at (s_memtime ticks, = shader cycles, per 100 MHz s_memrealtime tick).  The
+ * data-sheet peak (157.3 TFLOP/s) assumes 2.4 GHz; under full matrix load the part clocks lower. */
+int gfc_probe_mfma_peak(int mfmas_per_wave, float* tflops, float* shader_clock_ghz, void* stream);
+
 size_t gfc_sp_workspace_bytes(int B, int C, int H, int W);
 
 /* image [B,C,H,W] (C = 1 or 3, RGB -> grey fused) -> heat-map [B, 8*(H/8), 8*(W/8)] (softmax over
