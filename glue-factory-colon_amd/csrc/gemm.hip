@@ -33,6 +33,8 @@ struct GemmArgs {
   float alpha;
   int xcd_remap;  // gemm_nt_kernel: walk the tiles in XCD-contiguous order (runtime.h: GFC_XCD_REMAP)
   int wide_stores;  // every epilogue through the per-wave LDS transpose: float4 stores (runtime.h: GFC_GEMM_EPI)
+  int stagger;      // first-round workgroups start (wave slot & 3) * stagger * 8128 cycles late (GFC_GEMM_STAGGER)
+  int first_round;  // number of workgroups resident at once (4 per CU)
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
   unsigned long long* stamps;  // diagnostic build (tools/micro/gemm_timeline.py): 8 words per wave
 #endif
@@ -46,6 +48,10 @@ extern "C" void gfc_diag_set_gemm_stamps(void* p) { g_diag_stamps = (unsigned lo
   } while (0)
 #else
 #define GEMM_STAMP(i_) do {} while (0)
+#endif
+
+#ifndef GEMM_EPI_BATCH
+#define GEMM_EPI_BATCH 2  // steps of the transposed epilogue whose rotary / residual operands are requested together
 #endif
 
 // Epilogue shared by the GEMM kernels: bias / BN affine / alpha directly from the accumulator layout, or -- when
@@ -67,20 +73,39 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
       const int col = n0 + wn * WT + nt * 32 + l31;
       const bool col_ok = col < g.N;
       const int cc = col_ok ? col : g.N - 1;
-      const float bi = g.bias ? g.bias[cc] : 0.f;
-      const float sc = g.scale ? g.scale[cc] : 1.f;
-      const float sh = g.shift ? g.shift[cc] : 0.f;
+      float bi = g.bias ? g.bias[cc] : 0.f;
+      float sc = g.scale ? g.scale[cc] : 1.f;
+      float sh = g.shift ? g.shift[cc] : 0.f;
+      // The three loads must be WAITED FOR here, once, in straight-line code.  Left to hipcc, their first use sits
+      // inside the first predicated store block, the wait-count pass cannot prove at the block joins that it has
+      // happened, and it puts `s_waitcnt vmcnt(0)` in front of every one of the 64 stores -- which also waits for the
+      // previous STORE to be acknowledged: 64 serialized round trips, 46 k cycles per wave (tools/micro/gemm_timeline.py).
+      asm volatile("" : "+v"(bi), "+v"(sc), "+v"(sh));
+      const bool full = m0 + wm * WTM + MT * 32 <= g.M && n0 + wn * WT + MTN * 32 <= g.N;  // wave-uniform
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
+        const int row0 = m0 + wm * WTM + mt * 32;
+        if (full) {  // no predicates: one basic block, stores issue back to back
+          float* yp = Y + (size_t)(row0 + 4 * h) * g.ldy + col;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = m0 + wm * WTM + mt * 32 + acc_row(r, h);
-          float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
+          for (int r = 0; r < 16; ++r) {
+            const float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 1)
-          if (row < g.M && col_ok && v == 12345.678f) Y[(size_t)row * g.ldy + col] = v;  // diagnostic: no stores
-#else
-          if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
+            if (v == 12345.678f)  // diagnostic: no stores
 #endif
+            yp[(size_t)((r & 3) + 8 * (r >> 2)) * g.ldy] = v;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + acc_row(r, h);
+            const float v = ((acc[mt][nt][r] + bi) * sc + sh) * g.alpha;
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 1)
+            if (row < g.M && col_ok && v == 12345.678f) Y[(size_t)row * g.ldy + col] = v;  // diagnostic: no stores
+#else
+            if (row < g.M && col_ok) Y[(size_t)row * g.ldy + col] = v;
+#endif
+          }
         }
       }
     }
@@ -111,8 +136,67 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
   }
   const bool rot = g.rot_cos != nullptr && colb < g.rot_cols;
   const int rd = colb & 63;
+  // as in the direct path: the per-column operands are waited for here, once, outside the store blocks
+  asm volatile("" : "+v"(bi4.x), "+v"(bi4.y), "+v"(bi4.z), "+v"(bi4.w));
+  asm volatile("" : "+v"(sc4.x), "+v"(sc4.y), "+v"(sc4.z), "+v"(sc4.w));
+  asm volatile("" : "+v"(sh4.x), "+v"(sh4.y), "+v"(sh4.z), "+v"(sh4.w));
+  // wave-uniform fast path (whole 32 x WT patch inside the matrix, float4-aligned): the rotary / residual operands of
+  // ALL steps of a round are requested first, then the steps compute and store back to back.  vmcnt retires in order
+  // and counts stores too: a load issued behind a store cannot be waited for without waiting for that store's
+  // acknowledgement, so the per-step form (load, wait, store, load, wait, ...) serialises 16 store round trips per wave.
+  const bool rot_w = g.rot_cos != nullptr && n0 + wn * WT < g.rot_cols;  // rot_cols is a multiple of 64 >= WT
+  const bool fast = vec_ok && m0 + wm * WTM + MT * 32 <= g.M && n0 + wn * WT + WT <= g.N && !(rot_w && g.residual);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
+    if (fast) {
+      // batches of NB4 steps: operands of a batch first, then its steps (two register sets of NB4 float4: cos | sin,
+      // or the residual rows)
+      constexpr int NS = 32 / RPS, NB4 = NS < GEMM_EPI_BATCH ? NS : GEMM_EPI_BATCH;
+      const int row0 = m0 + wm * WTM + mt * 32 + er;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int nt = 0; nt < MTN; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int b0 = 0; b0 < NS; b0 += NB4) {
+        float4 opa[NB4], opb[NB4];
+        if (rot_w) {
+#pragma unroll
+          for (int i = 0; i < NB4; ++i) {
+            opa[i] = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)(row0 + RPS * (b0 + i)) * 64 + rd);
+            opb[i] = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)(row0 + RPS * (b0 + i)) * 64 + rd);
+          }
+        } else if (g.residual) {
+#pragma unroll
+          for (int i = 0; i < NB4; ++i)
+            opa[i] = *reinterpret_cast<const float4*>(g.residual + (size_t)(row0 + RPS * (b0 + i)) * g.ldy + colb);
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+          const int lr = er + RPS * (b0 + i);
+          float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
+          v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
+          if (rot_w) {
+            const float x = v.x, y = v.y, zz = v.z, w = v.w;
+            v.x = x * opa[i].x + (-y) * opb[i].x;
+            v.y = y * opa[i].y + x * opb[i].y;
+            v.z = zz * opa[i].z + (-w) * opb[i].z;
+            v.w = w * opa[i].w + zz * opb[i].w;
+          }
+          v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+          v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+          if (!rot_w && g.residual) {
+            v.x = opa[i].x + v.x; v.y = opa[i].y + v.y; v.z = opa[i].z + v.z; v.w = opa[i].w + v.w;
+          }
+          *reinterpret_cast<float4*>(Y + (size_t)(row0 + RPS * (b0 + i)) * g.ldy + colb) = v;
+        }
+      }
+      continue;
+    }
     // The patch is private to the wave and the K loop ended on a workgroup barrier: LDS operations of one wave
     // complete in order, so only the compiler has to be kept from reordering across the transpose.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -194,6 +278,15 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ?
     t -= bz * per_z;
     by = t / gridDim.x;
     bx = t - by * gridDim.x;
+  }
+  // De-phasing (K = 256 GEMMs are two lock-step rounds of four workgroups per CU: every CU stores its 64 KB tiles at
+  // the same moment, the chip-wide burst is HBM-write bound and the matrix pipe waits): the workgroups of the FIRST
+  // round start staggered by their wave slot, so that later K loops and epilogues of a CU interleave.
+  if (g.stagger > 0 && (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) < g.first_round) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const int naps = (int)(hw & 3u) * g.stagger;
+    for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(127);
   }
   const int m0 = by * GBM, n0 = bx * BN;
   const long long z = bz;
@@ -479,6 +572,10 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
     ga[nt] = gamma[col];
     be[nt] = beta[col];
   }
+  // waited for HERE, once (see gemm_epilogue: otherwise hipcc re-waits for gamma / beta inside every predicated store
+  // block, and a vmcnt wait behind stores also waits for those stores)
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) asm volatile("" : "+v"(bi[nt]), "+v"(ga[nt]), "+v"(be[nt]));
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -526,6 +623,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
     stat[BM + tid] = 1.f / sqrtf(var + 1e-5f);
   }
   __syncthreads();
+  const bool full_rows = m0 + BM <= g.M;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -536,7 +634,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * gq + j;
         const int row = m0 + wm * 64 + mt * 32 + acc_row(r, h);
-        if (row < g.M) {
+        if (full_rows || row < g.M) {  // full_rows: workgroup-uniform, no per-row predicate blocks
           float* yp = g.Y + (size_t)row * g.ldy + wn * 128 + l31;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
@@ -873,6 +971,8 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
   GemmArgs ga = g;
   ga.xcd_remap = gfc_knobs().xcd_remap != 0 && (long long)grid.x * grid.y * grid.z >= 16;
+  ga.stagger = gfc_knobs().gemm_stagger;
+  ga.first_round = gfc_device_cus() * 4;
   ga.wide_stores = gfc_knobs().gemm_epi == 1 && g.ldy % 4 == 0 && (reinterpret_cast<size_t>(g.Y) & 15) == 0 &&
                    g.strideY % 4 == 0;
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)

@@ -21,6 +21,7 @@ struct GfcKnobs {
   int ffn_fused;     // GFC_FFN_FUSED: -1 = automatic, 0 = GEMM + layernorm_gelu pass, 1 = row-owning fused GEMM
   int assign_mode;   // GFC_ASSIGN_MODE: 0 = automatic, 1 = five-pass tail, 2 = two-pass tail
   int gemm_epi;      // GFC_GEMM_EPI: 0 = automatic, 1 = float4 stores through the LDS transpose for every epilogue, 2 = direct
+  int gemm_stagger;  // GFC_GEMM_STAGGER: start skew of the first-round GEMM workgroups in units of 8128 cycles per wave slot
   int xcd_remap;     // GFC_XCD_REMAP: 1 (default) = XCD-aware work order (common.h: gfc_xcd_chunk), 0 = dispatch order
 };
 const GfcKnobs& gfc_knobs();
