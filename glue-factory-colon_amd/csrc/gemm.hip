@@ -50,9 +50,51 @@ extern "C" void gfc_diag_set_gemm_stamps(void* p) { g_diag_stamps = (unsigned lo
 #define GEMM_STAMP(i_) do {} while (0)
 #endif
 
-#ifndef GEMM_EPI_BATCH
-#define GEMM_EPI_BATCH 2  // steps of the transposed epilogue whose rotary / residual operands are requested together
-#endif
+// Fast path of the transposed epilogue for one 32-row round of a wave (whole patch inside the matrix, float4-aligned),
+// specialised by MODE (0 = bias / affine only, 1 = rotary, 2 = residual) so that the body is ONE basic block and the
+// wait counts hipcc inserts are exact.  The rotary / residual operands of step i + 1 are requested BEFORE the store of
+// step i: vmcnt retires in order and counts stores too, so a load issued behind a store cannot be waited for without
+// waiting for that store's acknowledgement (the per-step form -- load, wait, store, load, wait -- serialises 16 store
+// round trips per wave: 46 k cycles, tools/micro/gemm_timeline.py).
+template <int MODE, int NS, int RPS, int ELD>
+__device__ __forceinline__ void gemm_epilogue_round_fast(const GemmArgs& g, const float* patch, float* Y, int row0, int er,
+                                                         int ec, int colb, int rd, float4 bi4, float4 sc4, float4 sh4) {
+  float4 opa = make_float4(0.f, 0.f, 0.f, 0.f), opb = opa;
+  if constexpr (MODE == 1) {
+    opa = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row0 * 64 + rd);
+    opb = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row0 * 64 + rd);
+  } else if constexpr (MODE == 2) {
+    opa = *reinterpret_cast<const float4*>(g.residual + (size_t)row0 * g.ldy + colb);
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    float4 na = opa, nb = opb;
+    if (i + 1 < NS) {
+      const size_t rn = (size_t)(row0 + RPS * (i + 1));
+      if constexpr (MODE == 1) {
+        na = *reinterpret_cast<const float4*>(g.rot_cos + rn * 64 + rd);
+        nb = *reinterpret_cast<const float4*>(g.rot_sin + rn * 64 + rd);
+      } else if constexpr (MODE == 2) {
+        na = *reinterpret_cast<const float4*>(g.residual + rn * g.ldy + colb);
+      }
+    }
+    float4 v = *reinterpret_cast<const float4*>(patch + (er + RPS * i) * ELD + ec);
+    v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
+    if constexpr (MODE == 1) {
+      // rotary: out[d] = t[d]*cos[d] + rot(t)[d]*sin[d], rot(t)[2i] = -t[2i+1], rot(t)[2i+1] = t[2i]
+      const float x = v.x, y = v.y, zz = v.z, w = v.w;
+      v.x = x * opa.x + (-y) * opb.x;
+      v.y = y * opa.y + x * opb.y;
+      v.z = zz * opa.z + (-w) * opb.z;
+      v.w = w * opa.w + zz * opb.w;
+    }
+    v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
+    v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
+    if constexpr (MODE == 2) { v.x = opa.x + v.x; v.y = opa.y + v.y; v.z = opa.z + v.z; v.w = opa.w + v.w; }
+    *reinterpret_cast<float4*>(Y + (size_t)(row0 + RPS * i) * g.ldy + colb) = v;
+    opa = na; opb = nb;
+  }
+}
 
 // Epilogue shared by the GEMM kernels: bias / BN affine / alpha directly from the accumulator layout, or -- when
 // rotary or residual operands have to be loaded per element -- through a per-wave LDS transpose with float4 traffic.
@@ -149,9 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     if (fast) {
-      // batches of NB4 steps: operands of a batch first, then its steps (two register sets of NB4 float4: cos | sin,
-      // or the residual rows)
-      constexpr int NS = 32 / RPS, NB4 = NS < GEMM_EPI_BATCH ? NS : GEMM_EPI_BATCH;
+      constexpr int NS = 32 / RPS;
       const int row0 = m0 + wm * WTM + mt * 32 + er;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -161,40 +201,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int b0 = 0; b0 < NS; b0 += NB4) {
-        float4 opa[NB4], opb[NB4];
-        if (rot_w) {
-#pragma unroll
-          for (int i = 0; i < NB4; ++i) {
-            opa[i] = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)(row0 + RPS * (b0 + i)) * 64 + rd);
-            opb[i] = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)(row0 + RPS * (b0 + i)) * 64 + rd);
-          }
-        } else if (g.residual) {
-#pragma unroll
-          for (int i = 0; i < NB4; ++i)
-            opa[i] = *reinterpret_cast<const float4*>(g.residual + (size_t)(row0 + RPS * (b0 + i)) * g.ldy + colb);
-        }
-#pragma unroll
-        for (int i = 0; i < NB4; ++i) {
-          const int lr = er + RPS * (b0 + i);
-          float4 v = *reinterpret_cast<const float4*>(patch + lr * ELD + ec);
-          v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
-          if (rot_w) {
-            const float x = v.x, y = v.y, zz = v.z, w = v.w;
-            v.x = x * opa[i].x + (-y) * opb[i].x;
-            v.y = y * opa[i].y + x * opb[i].y;
-            v.z = zz * opa[i].z + (-w) * opb[i].z;
-            v.w = w * opa[i].w + zz * opb[i].w;
-          }
-          v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
-          v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
-          if (!rot_w && g.residual) {
-            v.x = opa[i].x + v.x; v.y = opa[i].y + v.y; v.z = opa[i].z + v.z; v.w = opa[i].w + v.w;
-          }
-          *reinterpret_cast<float4*>(Y + (size_t)(row0 + RPS * (b0 + i)) * g.ldy + colb) = v;
-        }
-      }
+      if (rot_w) gemm_epilogue_round_fast<1, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
+      else if (g.residual) gemm_epilogue_round_fast<2, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
+      else gemm_epilogue_round_fast<0, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
       continue;
     }
     // The patch is private to the wave and the K loop ended on a workgroup barrier: LDS operations of one wave
@@ -252,7 +261,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
 // underneath the MFMAs of the current one.
 template <int NW, int MT, int BK, int MTN = MT>
-__global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? (NW == 4 ? 4 : 3) : 2)) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? 4 : 2)) void gemm_nt_kernel(GemmArgs g) {
   constexpr int T = 128 * NW;        // threads
   constexpr int GBM = 64 * MT;       // tile height (2 waves)
   constexpr int BN = 32 * MTN * NW;  // tile width
