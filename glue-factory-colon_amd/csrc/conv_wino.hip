@@ -37,7 +37,7 @@
 #define WIM_R 20                   // STEM: image patch rows
 #define WIM_C 12                   // STEM: image patch columns
 #ifndef WINO_DIAG
-#define WINO_DIAG 0                // diagnostic builds (tools/ab_build.sh): 1 no conv1a, 2 no B reloads, 8 no patch loads, 16 no column transform, 64 no chunk barrier
+#define WINO_DIAG 0                // diagnostic builds (tools/ab_build.sh): 1 no conv1a, 2 no B reloads, 8 no patch loads, 16 no column transform, 64 no chunk barrier, 256 phase accounting (tools/micro/wino_timeline.py), 512 no output stores
 #endif
 
 struct WinoArgs {
@@ -378,6 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
       const int Ho = a.H >> 1, Wo = a.W >> 1;
       if (oy < Ho && ox < Wo) {
         const float4 u = yv[0][0], v = yv[0][1], w = yv[1][0], z = yv[1][1];
+        if (!(WINO_DIAG & 512) || oy < 0)  // diagnostic 512: no output stores
         *reinterpret_cast<float4*>(a.y + (((size_t)b * Ho + oy) * Wo + ox) * a.cout + co) =
             make_float4(fmaxf(fmaxf(u.x, v.x), fmaxf(w.x, z.x)), fmaxf(fmaxf(u.y, v.y), fmaxf(w.y, z.y)),
                         fmaxf(fmaxf(u.z, v.z), fmaxf(w.z, z.z)), fmaxf(fmaxf(u.w, v.w), fmaxf(w.w, z.w)));
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int gy = 2 * oy + i, gx = 2 * ox + j;
-          if (gy < a.H && gx < a.W)
+          if (gy < a.H && gx < a.W && (!(WINO_DIAG & 512) || gy < 0))  // diagnostic 512: no output stores
             *reinterpret_cast<float4*>(a.y + (((size_t)b * a.H + gy) * a.W + gx) * a.cout + co) = yv[i][j];
         }
     }

@@ -72,6 +72,10 @@ __device__ __forceinline__ float float_from_order_bits(unsigned int o) {
   return __uint_as_float(u);
 }
 
+// (no NaNs reach the pools: one v_max_f32 / v_max3_f32 instead of compare + select; the keep masks are 0 / 1 bytes)
+__device__ __forceinline__ float window_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ unsigned char window_max(unsigned char a, unsigned char b) { return a | b; }
+
 // One separable max / OR pass over the LDS image.  Each work item owns SEG consecutive positions of
 // one line and slides the (2*RAD+1) window through registers: SEG + 2*RAD LDS reads for SEG outputs.
 // ROW passes map consecutive lanes to consecutive lines (odd line stride RS -> conflict-free);
@@ -89,12 +93,20 @@ __device__ __forceinline__ void window_pass(const T* __restrict__ src, T lowest,
       const int idx = ROW ? line * RS + p : p * RS + line;
       w[j] = ok ? src[idx] : lowest;
     }
+    // max over 2 RAD + 1 taps from maxima of three: t3[j] = max(w[j..j+2]); 3 taps: t3[j]; 5: t3[j] | t3[j+2];
+    // 7: t3[j] | t3[j+2] | t3[j+4]; 9: t3[j] | t3[j+3] | t3[j+6]  (two v_max3 per output instead of 2 RAD compares)
+    static_assert(RAD >= 1 && RAD <= 4, "window_pass");
+    T t3[SEG + 2 * RAD - 2];
+#pragma unroll
+    for (int j = 0; j < SEG + 2 * RAD - 2; ++j) t3[j] = window_max(window_max(w[j], w[j + 1]), w[j + 2]);
 #pragma unroll
     for (int j = 0; j < SEG; ++j) {
       if (p0 + j < R) {
-        T m = w[j];
-#pragma unroll
-        for (int d = 1; d <= 2 * RAD; ++d) m = (w[j + d] > m) ? w[j + d] : m;
+        T m;
+        if constexpr (RAD == 1) m = t3[j];
+        else if constexpr (RAD == 2) m = window_max(t3[j], t3[j + 2]);
+        else if constexpr (RAD == 3) m = window_max(window_max(t3[j], t3[j + 2]), t3[j + 4]);
+        else m = window_max(window_max(t3[j], t3[j + 3]), t3[j + 6]);
         emit(ROW ? line * RS + p0 + j : (p0 + j) * RS + line, m);
       }
     }
