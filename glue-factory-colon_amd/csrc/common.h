@@ -41,6 +41,43 @@ __device__ __forceinline__ unsigned gfc_xcd_chunk(unsigned id, unsigned n) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
 }
 
+// erff, branch-free.  The device library's erff evaluates one of two polynomials behind a divergent branch (|x| < 1 or
+// not): inlined into an epilogue that is ~55 instructions and an exec-mask round trip per element, each element its own
+// basic block.  This is the SAME arithmetic -- the same coefficients, the same fma chain, the same expf(-p) reduction
+// (checked bit for bit against erff over all 2^32 inputs: tools/micro/erf_check.hip) -- with both polynomials evaluated
+// and one select, so that consecutive elements schedule into each other.
+__device__ __forceinline__ float gfc_erff(float x) {
+  const float ax = fabsf(x);
+  // |x| >= 1: 1 - exp(-p(|x|))
+  float p = fmaf(ax, __uint_as_float(0x378e98abu), __uint_as_float(0xb9c68948u));
+  p = fmaf(ax, p, __uint_as_float(0x3b7cd369u));
+  p = fmaf(ax, p, __uint_as_float(0xbcc618b2u));
+  p = fmaf(ax, p, __uint_as_float(0x3dda74e4u));
+  p = fmaf(ax, p, __uint_as_float(0x3f228afdu));
+  p = fmaf(ax, p, __uint_as_float(0x3e03c728u));
+  p = fmaf(ax, p, ax);
+  const float nl2e = __uint_as_float(0xbfb8aa3bu);  // -log2(e), high part
+  const float ph = nl2e * p;
+  float pl = fmaf(p, nl2e, -ph);
+  const float pr = rintf(ph);
+  pl = fmaf(p, __uint_as_float(0xb2a5705fu), pl);  // -log2(e), low part
+  float e = __builtin_amdgcn_exp2f((ph - pr) + pl);
+  e = ldexpf(e, (int)pr);
+  e = (__uint_as_float(0x42ce8ed0u) < p) ? 0.f : e;       // exp(-p) underflows
+  e = (__uint_as_float(0xc2b17218u) > p) ? INFINITY : e;  // (never for p >= 0; kept for bit-equality on NaN / -x paths)
+  const float big = 1.0f - e;
+  // |x| < 1: |x| + |x| q(x^2)
+  const float t = x * x;
+  float q = fmaf(t, __uint_as_float(0xba1345e1u), __uint_as_float(0x3ba10414u));
+  q = fmaf(t, q, __uint_as_float(0xbcdac9b8u));
+  q = fmaf(t, q, __uint_as_float(0x3de703beu));
+  q = fmaf(t, q, __uint_as_float(0xbec09330u));
+  q = fmaf(t, q, __uint_as_float(0x3e0375d0u));
+  const float small = fmaf(ax, q, ax);
+  const float r = !(ax < 1.0f) ? big : small;
+  return copysignf(r, x);
+}
+
 #define GFC_LAUNCH_CHECK()                                   \
   do {                                                       \
     if (hipGetLastError() != hipSuccess) return GFC_ERR_LAUNCH; \
