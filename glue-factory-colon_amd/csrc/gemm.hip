@@ -491,6 +491,17 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
   const float* A0 = g.A0;
   const float* A1 = g.A1;
   const int ktiles = (g.K0 + g.K1) / BK;
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  unsigned long long* stamp_base = g.stamps ? g.stamps + ((size_t)blockIdx.x * (4 * WM) + wave) * 8 : nullptr;
+  if (g.stamps && lane == 0) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    stamp_base[5] = hw;
+    stamp_base[6] = xcc;
+  }
+  GEMM_STAMP(0);
+#endif
 
   // staging: thread -> float4 column s_c4 of tile row s_r0 (weights: rows s_r0 + 128 i).  For the 16-deep tile the
   // rows are permuted inside blocks of 8 so that the ds_write_b128 is conflict-free (see gemm_nt_kernel).
@@ -541,6 +552,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
   GW_STORE(0);
   if (ktiles > 1) GW_LOAD(1);
   __syncthreads();
+  GEMM_STAMP(1);
   for (int kt = 0; kt < ktiles; ++kt) {
     if (kt + 1 < ktiles) {
       GW_STORE((kt + 1) & 1);
@@ -569,6 +581,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
   }
 #undef GW_LOAD
 #undef GW_STORE
+  GEMM_STAMP(2);
 
   // ---- epilogue: + bias, LayerNorm over the 512 columns of each row, GELU, store ----
   float* red = smem;          // [4][BM] per-column-wave row partials
@@ -632,6 +645,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
     stat[BM + tid] = 1.f / sqrtf(var + 1e-5f);
   }
   __syncthreads();
+  GEMM_STAMP(3);  // statistics done
   const bool full_rows = m0 + BM <= g.M;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -661,6 +675,9 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
       }
     }
   }
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  GEMM_STAMP(4);
+#endif
 }
 
 template <int WM>
@@ -669,7 +686,11 @@ static int launch_rows512(const GemmArgs& g, const float* gamma, const float* be
   constexpr size_t lds = (size_t)2 * (BM + GW_BN) * (BK + 4) * sizeof(float);
   static std::atomic<unsigned long long> lds_ok{0};
   if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_rows512_ln_gelu_kernel<WM>, lds, lds_ok);
-  hipLaunchKernelGGL(gemm_rows512_ln_gelu_kernel<WM>, dim3((g.M + BM - 1) / BM), dim3(256 * WM), lds, st, g, gamma, beta);
+  GemmArgs gd = g;
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  gd.stamps = g_diag_stamps;
+#endif
+  hipLaunchKernelGGL(gemm_rows512_ln_gelu_kernel<WM>, dim3((g.M + BM - 1) / BM), dim3(256 * WM), lds, st, gd, gamma, beta);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from glue_factory_colon_amd import _native as nat  # noqa: E402
 
+FFN = len(sys.argv) > 1 and sys.argv[1] == "ffn"  # the row-owning ffn[0] + LayerNorm + GELU kernel (N = 512, K = 256 + 256)
+if FFN:
+    sys.argv = [sys.argv[0], "512", "512"] + sys.argv[2:]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
@@ -29,7 +32,15 @@ b = torch.randn((N,), device=dev)
 Y = torch.empty((M, N), device=dev)
 
 
+gamma, beta = torch.rand((N,), device=dev) + 0.5, torch.randn((N,), device=dev)
+A1 = torch.randn((M, K // 2), device=dev)
+
+
 def run():
+    if FFN:
+        nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(A), K, K // 2, nat.ptr(A1), K // 2, K // 2, nat.ptr(W), K, nat.ptr(b),
+                                                nat.ptr(gamma), nat.ptr(beta), nat.ptr(Y), N, M, N, st), "ffn")
+        return
     nat.check(lib.gfc_linear(nat.ptr(A), K, K, None, 0, 0, nat.ptr(W), K, nat.ptr(b), None, None, 1.0, None, None, None, 0,
                              nat.ptr(Y), N, M, N, st), "linear")
 
@@ -45,8 +56,9 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 100
 print(f"M={M} N={N} K={K}: {us:.1f} us  {2 * M * N * K / us / 1e6:.1f} TFLOP/s")
-nwg = ((M + 127) // 128) * ((N + 127) // 128)
-stamps = torch.zeros((nwg * 4, 8), dtype=torch.int64, device=dev)
+nwg = ((M + 127) // 128) * (1 if FFN else (N + 127) // 128)
+WPW = 8 if FFN else 4  # waves per workgroup
+stamps = torch.zeros((nwg * WPW, 8), dtype=torch.int64, device=dev)
 raw.gfc_diag_set_gemm_stamps(stamps.data_ptr())
 run()
 torch.cuda.synchronize()
@@ -58,11 +70,12 @@ t = s[:, :5]
 hw, xcc = s[:, 5], s[:, 6] & 0xF
 print("waves", len(s), "stamped", int((t[:, 0] > 0).sum()))
 d = np.diff(t, axis=1)
-for name, col in zip(("prologue", "k loop", "epilogue", "store drain"), range(4)):
+for name, col in zip(("prologue", "k loop", "statistics" if FFN else "epilogue", "gelu + stores" if FFN else "store drain"), range(4)):
     v = d[:, col]
     print(f"{name:12s} median {np.median(v):9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles")
 life = t[:, 4] - t[:, 0]
-print(f"wave lifetime median {np.median(life):.0f}; MFMA cycles per wave {K // 2 * 4 * 64}")
+MF = K // 2 * (8 if FFN else 4) * 64  # MFMA issue cycles per wave
+print(f"wave lifetime median {np.median(life):.0f}; MFMA cycles per wave {MF}")
 simd = (hw >> 4) & 3
 cu = (xcc << 16) | ((hw >> 8) & 0xFF)
 keys = cu * 4 + simd
@@ -81,7 +94,7 @@ for k in np.unique(keys):
         else:
             cur_b = max(cur_b, b2)
     covered += cur_b - cur_a
-    mf = m.sum() * (K // 2 * 4 * 64)
+    mf = m.sum() * MF
     util.append(mf / span)
     cover.append(covered / span)
     spans.append(span)
