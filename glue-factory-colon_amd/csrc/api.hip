@@ -212,7 +212,7 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
 // ---------------------------------------------------------------------------------------------
 struct LgPlan {
   size_t R;
-  size_t x, qkv, msg, cosb, sinb, tables, total;
+  size_t x, qkv, msg, cosb, sinb, csb, tables, total;
 };
 
 extern "C" size_t gfc_lg_layer_workspace_bytes(int rows);
@@ -232,6 +232,7 @@ static LgPlan lg_plan(int B, int M, int N) {
   p.msg = take(p.R * 4 * 4);  // packed key points [R][2] (+ scales / orientations [R][2]) for the rotary tables
   p.cosb = take(p.R * 64 * 4);
   p.sinb = take(p.R * 64 * 4);
+  p.csb = take(p.R * 64 * 4);  // the same values packed (cos, sin) per frequency: what the QKV epilogue reads
   p.tables = take((size_t)B * (2 * 4 * 2 + 2 + 2 + 4) * 4 + 256);
   p.total = off;
   return p;
@@ -276,9 +277,20 @@ extern "C" size_t gfc_lg_layer_workspace_bytes(int rows) {
          gfc_align((size_t)rows * 512 * 4) + lg_attn_scratch_bytes(rows);
 }
 
+static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, const float* csb,
+                         int R, const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
+                         size_t ws_bytes, void* stream);
+
 extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, int R,
                             const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
                             size_t ws_bytes, void* stream) {
+  return lg_layer_impl(p, l, x, cosb, sinb, nullptr, R, self_p, cross_p, n_problems, maxn, ws, ws_bytes, stream);
+}
+
+// csb (optional): the rotary table packed for the QKV epilogue (one float4 per four channels instead of two)
+static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, const float* csb,
+                         int R, const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
+                         size_t ws_bytes, void* stream) {
   if (!p || !x || !cosb || !sinb || !self_p || !cross_p || !ws || R <= 0 || n_problems <= 0 || maxn <= 0)
     return GFC_ERR_INVALID;
   if (l < 0 || l >= p->n_layers) return GFC_ERR_INVALID;
@@ -325,8 +337,11 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
   {
 
     // ---- self block (lightglue.py:151-164) ----
-    GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
-                768));
+    if (csb && !split)
+      GFC_TRY(gfc_linear_rot_packed(x, D, D, p->wqkv[l], D, p->bqkv[l], csb, 512, qkv, 768, R, 768, st));
+    else
+      GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
+                  768));
     GFC_TRY(attn(qkv, 768, qkv + 256, 768, qkv + 512, 768, self_p));
     // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
     // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
@@ -460,7 +475,8 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
     if (hipMemcpyAsync(so + (size_t)R0 * 2, scale_ori1, (size_t)R1 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
       return GFC_ERR_LAUNCH;
   }
-  GFC_TRY(gfc_lg_posenc(msg, so, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, pdim, cosb, sinb, st));
+  float* csb = (float*)(base + pl.csb);
+  GFC_TRY(gfc_lg_posenc_packed(msg, so, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, pdim, cosb, sinb, csb, st));
 
   // descriptors -> x (input_proj when input_dim != 256, lightglue.py:352-355,464-465)
   if (p->input_dim == D) {
@@ -477,8 +493,8 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
 
   const int maxn = M > N ? M : N;
   for (int l = 0; l < p->n_layers; ++l)
-    GFC_TRY(gfc_lg_layer(p, l, x, cosb, sinb, R, self_p, cross_p, 2 * B, maxn, base + pl.qkv,
-                         gfc_lg_layer_workspace_bytes(R), st));
+    GFC_TRY(lg_layer_impl(p, l, x, cosb, sinb, csb, R, self_p, cross_p, 2 * B, maxn, base + pl.qkv,
+                          gfc_lg_layer_workspace_bytes(R), st));
 
   if (ref_desc0 && hipMemcpyAsync(ref_desc0, x, (size_t)R0 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
     return GFC_ERR_LAUNCH;

@@ -83,4 +83,11 @@ __device__ __forceinline__ float gfc_erff(float x) {
     if (hipGetLastError() != hipSuccess) return GFC_ERR_LAUNCH; \
   } while (0)
 
+// library-internal variants (not part of the C ABI): rotary operands as ONE packed table [rows][32 frequencies][cos, sin]
+int gfc_lg_posenc_packed(const float* kpts, const float* scale_ori, const float* sizes, const int32_t* row0,
+                         const int32_t* n, int n_images, int max_n, const float* wr, int dim, float* cos_out, float* sin_out,
+                         float* cs_out, void* stream);
+int gfc_linear_rot_packed(const float* A0, int lda0, int K0, const float* W, int ldw, const float* bias, const float* rot_cs,
+                          int rot_cols, float* Y, int ldy, int M, int N, void* stream);
+
 static inline size_t gfc_align(size_t x) { return (x + 255) & ~(size_t)255; }

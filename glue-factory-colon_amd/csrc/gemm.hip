@@ -26,6 +26,7 @@ struct GemmArgs {
   const float* residual;
   const float* rot_cos;
   const float* rot_sin;
+  const float* rot_cs;  // alternative to rot_cos / rot_sin: packed [M][32][cos, sin] (library-internal, gfc_linear_rot_packed)
   float* Y;
   long long strideA, strideW, strideY;  // batch strides (blockIdx.z)
   int lda0, lda1, ldw, ldy;
@@ -65,6 +66,8 @@ __device__ __forceinline__ void gemm_epilogue_round_fast(const GemmArgs& g, cons
     opb = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row0 * 64 + rd);
   } else if constexpr (MODE == 2) {
     opa = *reinterpret_cast<const float4*>(g.residual + (size_t)row0 * g.ldy + colb);
+  } else if constexpr (MODE == 3) {
+    opa = *reinterpret_cast<const float4*>(g.rot_cs + (size_t)row0 * 64 + rd);
   }
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
@@ -76,6 +79,8 @@ __device__ __forceinline__ void gemm_epilogue_round_fast(const GemmArgs& g, cons
         nb = *reinterpret_cast<const float4*>(g.rot_sin + rn * 64 + rd);
       } else if constexpr (MODE == 2) {
         na = *reinterpret_cast<const float4*>(g.residual + rn * g.ldy + colb);
+      } else if constexpr (MODE == 3) {
+        na = *reinterpret_cast<const float4*>(g.rot_cs + rn * 64 + rd);
       }
     }
     float4 v = *reinterpret_cast<const float4*>(patch + (er + RPS * i) * ELD + ec);
@@ -87,6 +92,13 @@ __device__ __forceinline__ void gemm_epilogue_round_fast(const GemmArgs& g, cons
       v.y = y * opa.y + x * opb.y;
       v.z = zz * opa.z + (-w) * opb.z;
       v.w = w * opa.w + zz * opb.w;
+    }
+    if constexpr (MODE == 3) {  // opa = (cos f, sin f, cos f+1, sin f+1): the same products as MODE 1
+      const float x = v.x, y = v.y, zz = v.z, w = v.w;
+      v.x = x * opa.x + (-y) * opa.y;
+      v.y = y * opa.x + x * opa.y;
+      v.z = zz * opa.z + (-w) * opa.w;
+      v.w = w * opa.z + zz * opa.w;
     }
     v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
     v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
@@ -107,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
   const int l31 = lane & 31, h = lane >> 5;
   // (workgroup-uniform: column tiles at or beyond rot_cols -- the V third of the fused QKV projection -- carry no
   // rotary and take the direct path as well)
-  if ((g.rot_cos == nullptr || n0 >= g.rot_cols) && g.residual == nullptr && !g.wide_stores) {
+  if (((g.rot_cos == nullptr && g.rot_cs == nullptr) || n0 >= g.rot_cols) && g.residual == nullptr && !g.wide_stores) {
     // plain epilogue: straight from the accumulator layout (column on the lane, rows in registers);
     // measured faster than the LDS transpose below when nothing has to be loaded per element
 #pragma unroll
@@ -176,7 +188,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
       if (g.scale) { sp4[j] = g.scale[cc]; hp4[j] = g.shift[cc]; }
     }
   }
-  const bool rot = g.rot_cos != nullptr && colb < g.rot_cols;
+  const bool rot = (g.rot_cos != nullptr || g.rot_cs != nullptr) && colb < g.rot_cols;
   const int rd = colb & 63;
   // as in the direct path: the per-column operands are waited for here, once, outside the store blocks
   asm volatile("" : "+v"(bi4.x), "+v"(bi4.y), "+v"(bi4.z), "+v"(bi4.w));
@@ -186,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
   // ALL steps of a round are requested first, then the steps compute and store back to back.  vmcnt retires in order
   // and counts stores too: a load issued behind a store cannot be waited for without waiting for that store's
   // acknowledgement, so the per-step form (load, wait, store, load, wait, ...) serialises 16 store round trips per wave.
-  const bool rot_w = g.rot_cos != nullptr && n0 + wn * WT < g.rot_cols;  // rot_cols is a multiple of 64 >= WT
+  const bool rot_w = (g.rot_cos != nullptr || g.rot_cs != nullptr) && n0 + wn * WT < g.rot_cols;  // rot_cols % 64 == 0
   const bool fast = vec_ok && m0 + wm * WTM + MT * 32 <= g.M && n0 + wn * WT + WT <= g.N && !(rot_w && g.residual);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -201,7 +213,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
         for (int r = 0; r < 16; ++r) patch[acc_row(r, h) * ELD + nt * 32 + l31] = acc[mt][nt][r];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      if (rot_w) gemm_epilogue_round_fast<1, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
+      if (rot_w && g.rot_cs) gemm_epilogue_round_fast<3, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
+      else if (rot_w) gemm_epilogue_round_fast<1, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
       else if (g.residual) gemm_epilogue_round_fast<2, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
       else gemm_epilogue_round_fast<0, NS, RPS, ELD>(g, patch, Y, row0, er, ec, colb, rd, bi4, sc4, sh4);
       continue;
@@ -225,8 +238,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
       v.x += bi4.x; v.y += bi4.y; v.z += bi4.z; v.w += bi4.w;
       if (rot) {
         // rotary: out[d] = t[d]*cos[d] + rot(t)[d]*sin[d], rot(t)[2i] = -t[2i+1], rot(t)[2i+1] = t[2i]
-        const float4 c = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row * 64 + rd);
-        const float4 sn = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row * 64 + rd);
+        float4 c, sn;
+        if (g.rot_cs) {
+          const float4 cs = *reinterpret_cast<const float4*>(g.rot_cs + (size_t)row * 64 + rd);
+          c = make_float4(cs.x, cs.x, cs.z, cs.z);
+          sn = make_float4(cs.y, cs.y, cs.w, cs.w);
+        } else {
+          c = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row * 64 + rd);
+          sn = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row * 64 + rd);
+        }
         const float x = v.x, y = v.y, zz = v.z, w = v.w;
         v.x = x * c.x + (-y) * sn.x;
         v.y = y * c.y + x * sn.y;
@@ -1051,6 +1071,17 @@ extern "C" int gfc_linear(const float* A0, int lda0, int K0, const float* A1, in
   g.strideA = g.strideW = g.strideY = 0;
   g.lda0 = lda0; g.lda1 = lda1; g.ldw = ldw; g.ldy = ldy;
   g.K0 = K0; g.K1 = K1; g.M = M; g.N = N; g.rot_cols = rot_cols; g.alpha = alpha;
+  return launch_gemm(g, 1, (hipStream_t)stream);
+}
+
+int gfc_linear_rot_packed(const float* A0, int lda0, int K0, const float* W, int ldw, const float* bias, const float* rot_cs,
+                          int rot_cols, float* Y, int ldy, int M, int N, void* stream) {
+  if (!A0 || !W || !Y || !rot_cs || M <= 0 || N <= 0 || K0 <= 0 || K0 % GBK || rot_cols % 64 || lda0 % 4 || ldw % 4)
+    return GFC_ERR_INVALID;
+  GemmArgs g = {};
+  g.A0 = A0; g.W = W; g.bias = bias; g.rot_cs = rot_cs; g.Y = Y;
+  g.lda0 = lda0; g.ldw = ldw; g.ldy = ldy;
+  g.K0 = K0; g.K1 = 0; g.M = M; g.N = N; g.rot_cols = rot_cols; g.alpha = 1.f;
   return launch_gemm(g, 1, (hipStream_t)stream);
 }
 

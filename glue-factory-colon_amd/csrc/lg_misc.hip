@@ -9,7 +9,7 @@
 __global__ void posenc_kernel(const float* __restrict__ kpts, const float* __restrict__ scale_ori,
                               const float* __restrict__ sizes, const int* __restrict__ row0,
                               const int* __restrict__ nrows, const float* __restrict__ wr, int dim,
-                              float* __restrict__ cos_out, float* __restrict__ sin_out) {
+                              float* __restrict__ cos_out, float* __restrict__ sin_out, float* __restrict__ cs_out) {
   const int img = blockIdx.y;
   const int n = nrows[img];
   const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (row, freq)
@@ -29,18 +29,27 @@ __global__ void posenc_kernel(const float* __restrict__ kpts, const float* __res
   const float c = cosf(p), s = sinf(p);
   *reinterpret_cast<float2*>(cos_out + row * 64 + 2 * f) = make_float2(c, c);
   *reinterpret_cast<float2*>(sin_out + row * 64 + 2 * f) = make_float2(s, s);
+  // packed table for the QKV GEMM's epilogue (library-internal): (cos, sin) of frequency f side by side, so that ONE
+  // float4 holds everything the rotation of four consecutive channels needs
+  if (cs_out) *reinterpret_cast<float2*>(cs_out + row * 64 + 2 * f) = make_float2(c, s);
+}
+
+int gfc_lg_posenc_packed(const float* kpts, const float* scale_ori, const float* sizes, const int32_t* row0,
+                         const int32_t* n, int n_images, int max_n, const float* wr, int dim, float* cos_out, float* sin_out,
+                         float* cs_out, void* stream) {
+  if (!kpts || !sizes || !row0 || !n || !wr || !cos_out || !sin_out || n_images <= 0 || max_n <= 0) return GFC_ERR_INVALID;
+  if ((dim != 2 && dim != 4) || ((dim == 4) != (scale_ori != nullptr))) return GFC_ERR_INVALID;
+  dim3 grid((max_n * 32 + 255) / 256, n_images);
+  hipLaunchKernelGGL(posenc_kernel, grid, dim3(256), 0, (hipStream_t)stream, kpts, scale_ori, sizes, row0, n, wr, dim,
+                     cos_out, sin_out, cs_out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
 }
 
 extern "C" int gfc_lg_posenc(const float* kpts, const float* scale_ori, const float* sizes, const int32_t* row0,
                              const int32_t* n, int n_images, int max_n, const float* wr, int dim, float* cos_out,
                              float* sin_out, void* stream) {
-  if (!kpts || !sizes || !row0 || !n || !wr || !cos_out || !sin_out || n_images <= 0 || max_n <= 0) return GFC_ERR_INVALID;
-  if ((dim != 2 && dim != 4) || ((dim == 4) != (scale_ori != nullptr))) return GFC_ERR_INVALID;
-  dim3 grid((max_n * 32 + 255) / 256, n_images);
-  hipLaunchKernelGGL(posenc_kernel, grid, dim3(256), 0, (hipStream_t)stream, kpts, scale_ori, sizes, row0, n, wr, dim,
-                     cos_out, sin_out);
-  GFC_LAUNCH_CHECK();
-  return GFC_OK;
+  return gfc_lg_posenc_packed(kpts, scale_ori, sizes, row0, n, n_images, max_n, wr, dim, cos_out, sin_out, nullptr, stream);
 }
 
 // ------------------------------------------------------------------------------------------

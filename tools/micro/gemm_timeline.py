@@ -14,6 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from glue_factory_colon_amd import _native as nat  # noqa: E402
 
+ROT = len(sys.argv) > 1 and sys.argv[1] == "rot"  # QKV GEMM: N = 768, rotary epilogue on the first 512 columns
+if ROT:
+    sys.argv = [sys.argv[0], "768", "256"] + sys.argv[2:]
 FFN = len(sys.argv) > 1 and sys.argv[1] == "ffn"  # the row-owning ffn[0] + LayerNorm + GELU kernel (N = 512, K = 256 + 256)
 if FFN:
     sys.argv = [sys.argv[0], "512", "512"] + sys.argv[2:]
@@ -36,7 +39,14 @@ gamma, beta = torch.rand((N,), device=dev) + 0.5, torch.randn((N,), device=dev)
 A1 = torch.randn((M, K // 2), device=dev)
 
 
+cos_t, sin_t = torch.rand((M, 64), device=dev), torch.rand((M, 64), device=dev)
+
+
 def run():
+    if ROT:
+        nat.check(lib.gfc_linear(nat.ptr(A), K, K, None, 0, 0, nat.ptr(W), K, nat.ptr(b), None, None, 1.0, None, nat.ptr(cos_t),
+                                 nat.ptr(sin_t), 512, nat.ptr(Y), N, M, N, st), "linear")
+        return
     if FFN:
         nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(A), K, K // 2, nat.ptr(A1), K // 2, K // 2, nat.ptr(W), K, nat.ptr(b),
                                                 nat.ptr(gamma), nat.ptr(beta), nat.ptr(Y), N, M, N, st), "ffn")
