@@ -332,6 +332,16 @@ __global__ __launch_bounds__(256) void assign_finalize_argmax_kernel(
       bv[q] = -INFINITY;
       bi[q] = 0x7FFFFFFF;
     }
+    // whole chunk inside the matrix (N = 1024: always): the 16 elements of a row are requested together and the NEXT
+    // row's before this row is stored -- in the per-element form (load, wait, store; vmcnt retires in order and counts
+    // stores) every load waited for the previous store's acknowledgement
+    const bool full_chunk = c0 + AS_NC * 64 <= N;
+    float xs[AS_NC], xn[AS_NC];
+    if (full_chunk && i0 + wave < M) {
+      const float* row = p + (size_t)(i0 + wave) * ld + c0 + lane;
+#pragma unroll
+      for (int q = 0; q < AS_NC; ++q) xs[q] = row[64 * q];
+    }
     for (int r = wave; r < AS_RB; r += 4) {
       const int i = i0 + r;
       if (i >= M) break;
@@ -341,6 +351,26 @@ __global__ __launch_bounds__(256) void assign_finalize_argmax_kernel(
       float* row = p + (size_t)i * ld + c0 + lane;
       float best = -INFINITY;
       int arg = 0x7FFFFFFF;
+      if (full_chunk) {
+        if (r + 4 < AS_RB && i + 4 < M) {
+#pragma unroll
+          for (int q = 0; q < AS_NC; ++q) xn[q] = row[(size_t)4 * ld + 64 * q];
+        }
+#pragma unroll
+        for (int q = 0; q < AS_NC; ++q) {
+          const int j = c0 + lane + 64 * q;
+          const float x = xs[q];
+          const float s0 = (x - rm) - rl;
+          const float s1 = (x - cmx[q]) - clg[q];
+          const float cert = lz0 + lz1[q];
+          const float v = (s0 + s1) + cert;
+          row[64 * q] = v;
+          if (v > best || arg == 0x7FFFFFFF) { best = v; arg = j; }
+          if (v > bv[q] || bi[q] == 0x7FFFFFFF) { bv[q] = v; bi[q] = i; }
+        }
+#pragma unroll
+        for (int q = 0; q < AS_NC; ++q) xs[q] = xn[q];
+      } else
 #pragma unroll
       for (int q = 0; q < AS_NC; ++q) {
         const int j = c0 + lane + 64 * q;
