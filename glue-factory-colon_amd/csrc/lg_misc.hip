@@ -261,8 +261,12 @@ __global__ __launch_bounds__(256) void assign_stats_kernel(const float* __restri
       // column statistics: online (max, sum of exp) per owned column
 #pragma unroll
       for (int q = 0; q < AS_NC; ++q) {
+        // one exponential, no divergent branch: exp(m - x) for x > m and exp(x - m) otherwise are both exp(-|x - m|)
         const float x = v[q];
-        if (x > m[q]) { sacc[q] = sacc[q] * expf(m[q] - x) + 1.f; m[q] = x; } else { sacc[q] += expf(x - m[q]); }
+        const bool up = x > m[q];
+        const float e = expf(up ? m[q] - x : x - m[q]);
+        sacc[q] = up ? sacc[q] * e + 1.f : sacc[q] + e;
+        m[q] = up ? x : m[q];
       }
     }
 #pragma unroll
