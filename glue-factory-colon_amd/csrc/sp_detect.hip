@@ -575,16 +575,26 @@ __global__ __launch_bounds__(256) void sample_kernel(const float* __restrict__ d
 #pragma unroll
   for (int v = 0; v < VPL; ++v) acc[v] = make_float4(0, 0, 0, 0);
   const float* db = dense + (size_t)b * h * w * D;
+  // the four corners are requested together (clamped addresses; a corner outside the map is skipped below): one
+  // memory round trip per key point instead of four dependent ones
+  float4 cval[4][VPL];
+  bool inside[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int xx = x0 + (c & 1), yy = y0 + (c >> 1);
-    if (xx < 0 || xx >= w || yy < 0 || yy >= h) continue;  // zeros padding (wave-uniform)
-    const float* p = db + ((size_t)yy * w + xx) * D;
+    inside[c] = !(xx < 0 || xx >= w || yy < 0 || yy >= h);  // zeros padding (wave-uniform)
+    const float* p = db + ((size_t)min(max(yy, 0), h - 1) * w + min(max(xx, 0), w - 1)) * D;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) cval[c][v] = *reinterpret_cast<const float4*>(p + (v * 64 + lane) * 4);
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (!inside[c]) continue;
     float4 val[VPL];
     float ss = 0.f;
 #pragma unroll
     for (int v = 0; v < VPL; ++v) {
-      val[v] = *reinterpret_cast<const float4*>(p + (v * 64 + lane) * 4);
+      val[v] = cval[c][v];
       ss += val[v].x * val[v].x + val[v].y * val[v].y + val[v].z * val[v].z + val[v].w * val[v].w;
     }
     ss = wave_sum(ss);
