@@ -457,6 +457,31 @@ def test_gemm_tile_variants_via_knob():
         assert r.returncode == 0, (tile, r.stdout[-800:], r.stderr[-400:])
 
 
+def test_gemm_epilogue_variants_via_knob():
+    """GFC_GEMM_EPI=1 (every epilogue through the LDS transpose: float4 stores) and GFC_GEMM_STAGGER (first-round
+    workgroups start skewed) select other code paths of the same GEMMs: same tests, including the batch-32 shapes that
+    take the unpredicated full-tile paths and ragged ones that take the predicated paths."""
+    import subprocess
+    import sys
+
+    for knobs in ({"GFC_GEMM_EPI": "1"}, {"GFC_GEMM_STAGGER": "2"}):
+        env = dict(os.environ, **knobs)
+        r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                            "linear_plain or linear_concat or linear_rotary or batched_nt or natural_dispatch_batch32",
+                            "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, (knobs, r.stdout[-800:], r.stderr[-400:])
+
+
+def test_mfma_peak_probe():
+    """bench-only gfc_probe_mfma_peak: a plausible fp32-MFMA rate and shader clock for an MI355X."""
+    import ctypes
+
+    tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
+    nat.check(nat.lib().gfc_probe_mfma_peak(20000, ctypes.byref(tf), ctypes.byref(ghz), st()), "probe")
+    assert 60.0 < tf.value < 165.0 and 1.0 < ghz.value < 2.6, (tf.value, ghz.value)
+    assert nat.lib().gfc_probe_mfma_peak(2, ctypes.byref(tf), ctypes.byref(ghz), st()) != 0  # GFC_ERR_INVALID
+
+
 def test_attention_variants_via_knob():
     """attention_kernel<2,4> (GFC_ATTN_CFG=1: two 32-query tiles per wave, 256 queries per workgroup -- what a
     32-pair batch dispatches to) and <1,2> (cfg 3) on the ragged shapes of test_attention (n_q not a multiple of
