@@ -365,9 +365,10 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int co = nb * CNB + nt * 32 + l31;
-        const float bi = a.bias[co];
-        const float sc = a.scale ? a.scale[co] : 1.f;
-        const float sh = a.shift ? a.shift[co] : 0.f;
+        float bi = a.bias[co];
+        float sc = a.scale ? a.scale[co] : 1.f;
+        float sh = a.shift ? a.shift[co] : 0.f;
+        asm volatile("" : "+v"(bi), "+v"(sc), "+v"(sh));
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           float t = acc[mt][nt][r] + bi;
@@ -389,9 +390,12 @@ __global__ __launch_bounds__(256, (KC == 16 && !PERSIST) ? 3 : 2) void conv3x3_m
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
       const int co = nb * CNB + nt * 32 + l31;
-      const float bi = a.bias[co];
-      const float sc = a.scale ? a.scale[co] : 1.f;
-      const float sh = a.shift ? a.shift[co] : 0.f;
+      float bi = a.bias[co];
+      float sc = a.scale ? a.scale[co] : 1.f;
+      float sh = a.shift ? a.shift[co] : 0.f;
+      // waited for once, here: otherwise hipcc re-waits (vmcnt(0)) inside every predicated store block below, and each
+      // of those waits also waits for the previous store (see gemm.hip: gemm_epilogue)
+      asm volatile("" : "+v"(bi), "+v"(sc), "+v"(sh));
       // rows 2*wave (mt 0) and 2*wave + 1 (mt 1) are vertical neighbours, register r and r+1 horizontal ones;
       // registers 8..15 are the same for the rows 8 further down
       float v0[16], v1[16];
