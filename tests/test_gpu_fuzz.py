@@ -1,4 +1,5 @@
-"""Randomised shape sweep of the hand-written kernels with ragged edges (Winograd convolution at any H x W / channel
+"""Randomised shape sweep of the hand-written kernels with ragged edges (GEMM epilogues at any M x N, attention problem
+sets, Winograd convolution at any H x W / channel
 count / pooling, the DISK window-NMS + top-n selection, the assignment head at any m x n) against torch float64 and the
 oracle; the sweep itself is tools/micro/fuzz_shapes.py so that it can be run for longer by hand."""
 import os

@@ -1,4 +1,5 @@
-"""Randomised shape sweep of gfc_conv3x3_wino / gfc_lg_assign / gfc_disk_nms_select against torch float64 / the oracle
+"""Randomised shape sweep of gfc_conv3x3_wino / gfc_lg_assign / gfc_disk_nms_select / gfc_linear / gfc_attention against
+torch float64 / the oracle
 (run on the GPU box: python tools/micro/fuzz_shapes.py [n_cases]).  Prints the worst error and any failing shape."""
 import ctypes
 import os
@@ -105,6 +106,88 @@ def run(n_cases=60, seed=2024):
         if not (err < 1e-4 and torch.equal(m0.cpu(), r0) and torch.equal(m1.cpu(), r1)):
             bad.append(("assign", b, m, n, err, int((m0.cpu() != r0).sum()), int((m1.cpu() != r1).sum())))
     print("assign: worst", worst, "bad", bad)
+    failures += bad
+
+    # ---- gfc_linear: ragged M / N, both K sources, every epilogue (bias, affine, alpha, rotary, residual) ----
+    bad, worst = [], 0.0
+    for case in range(n_cases):
+        m, n = ri(1, 900), ri(1, 12) * 64 if ri(0, 1) else ri(1, 700)
+        k0, k1 = ri(1, 8) * 32, ri(0, 1) * ri(1, 4) * 32
+        mode = ri(0, 3)  # 0 plain, 1 affine + alpha, 2 rotary (first rot_cols columns), 3 residual
+        if mode == 2:
+            n = ri(1, 12) * 64
+        a0 = torch.randn((m, k0), generator=g)
+        a1 = torch.randn((m, k1), generator=g) if k1 else None
+        w = torch.randn((n, k0 + k1), generator=g) / (k0 + k1) ** 0.5
+        bias = torch.randn((n,), generator=g) * 0.1 if ri(0, 3) else None
+        ref = torch.cat([a0, a1], 1).double() if k1 else a0.double()
+        ref = ref @ w.double().t()
+        if bias is not None:
+            ref = ref + bias.double()
+        scale = shift = res = cos = sin = None
+        alpha, rot_cols = 1.0, 0
+        if mode == 1:
+            scale, shift, alpha = torch.rand((n,), generator=g) + 0.5, torch.randn((n,), generator=g) * 0.1, 0.25
+            ref = (ref * scale.double() + shift.double()) * alpha
+        elif mode == 2:
+            rot_cols = ri(1, n // 64) * 64
+            ang = torch.randn((m, 32), generator=g) * 2
+            cos, sin = ang.cos().repeat_interleave(2, -1), ang.sin().repeat_interleave(2, -1)
+            t = ref[:, :rot_cols].reshape(m, rot_cols // 64, 64)
+            rot = torch.stack([-t[..., 1::2], t[..., 0::2]], -1).reshape(t.shape)
+            ref = torch.cat([(t * cos.double()[:, None] + rot * sin.double()[:, None]).reshape(m, rot_cols), ref[:, rot_cols:]], 1)
+        elif mode == 3:
+            res = torch.randn((m, n), generator=g)
+            ref = ref + res.double()
+        dd = lambda t: None if t is None else t.to(DEV).contiguous()  # noqa: E731
+        keep = [dd(t) for t in (a0, a1, w, bias, scale, shift, res, cos, sin)]
+        y = torch.full((m, n), float("nan"), device=DEV)
+        rc = lib.gfc_linear(nat.ptr(keep[0]), k0, k0, nat.ptr(keep[1]), k1, k1, nat.ptr(keep[2]), k0 + k1, nat.ptr(keep[3]),
+                            nat.ptr(keep[4]), nat.ptr(keep[5]), alpha, nat.ptr(keep[6]), nat.ptr(keep[7]), nat.ptr(keep[8]),
+                            rot_cols, nat.ptr(y), n, m, n, st)
+        torch.cuda.synchronize()
+        if n % 4 and mode == 3:  # unaligned residual rows: allowed to be refused
+            if rc != 0:
+                continue
+        err = float("nan") if rc != 0 else ((y.double().cpu() - ref).abs() / (1 + ref.abs())).max().item()
+        worst = max(worst, err if err == err else 0.0)
+        if not err < 3e-5:
+            bad.append(("linear", m, n, k0, k1, mode, rot_cols, rc, err))
+    print("linear: worst", worst, "bad", bad)
+    failures += bad
+
+    # ---- gfc_attention: ragged problem sets, with and without the key-split scratch ----
+    bad, worst = [], 0.0
+    for case in range(max(n_cases // 4, 8)):
+        shapes = [(ri(1, 600), ri(1, 600)) for _ in range(ri(1, 4))]
+        rows = sum(max(a, b) for a, b in shapes)
+        q, k, v = (torch.randn((rows, 256), generator=g) * s for s in (1.5, 1.5, 1.0))
+        probs, r0 = [], 0
+        for nq, nk in shapes:
+            probs.append([r0, nq, r0, nk])
+            r0 += max(nq, nk)
+        qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+        o = torch.full((rows, 256), float("nan"), device=DEV)
+        pt = torch.tensor(probs, dtype=torch.int32, device=DEV)
+        max_nq = max(a for a, _ in shapes)
+        ws = None
+        if ri(0, 1):
+            nb = lib.gfc_attention_workspace_bytes(len(shapes), max_nq, 4)
+            ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=DEV) if nb else None
+        nat.check(lib.gfc_attention(nat.ptr(qd), 256, nat.ptr(kd), 256, nat.ptr(vd), 256, nat.ptr(o), 256, nat.ptr(pt),
+                                    len(shapes), max_nq, 4, 0.125, nat.ptr(ws), 0 if ws is None else ws.numel(), st), "attention")
+        torch.cuda.synchronize()
+        oc = o.cpu()
+        for r, nq, _, nk in probs:
+            qq = q[r:r + nq].double().view(nq, 4, 64).transpose(0, 1)
+            kk = k[r:r + nk].double().view(nk, 4, 64).transpose(0, 1)
+            vv = v[r:r + nk].double().view(nk, 4, 64).transpose(0, 1)
+            ref = (torch.softmax(qq @ kk.transpose(1, 2) * 0.125, -1) @ vv).transpose(0, 1).reshape(nq, 256)
+            err = (oc[r:r + nq].double() - ref).abs().max().item()
+            worst = max(worst, err if err == err else 0.0)
+            if not err < 2e-5:
+                bad.append(("attention", shapes, (nq, nk), err))
+    print("attention: worst", worst, "bad", bad)
     return failures + bad
 
 if __name__ == "__main__":
