@@ -273,7 +273,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 }
 
 // 2 x NW waves; every wave owns MT x MT MFMA tiles of 32x32.
-//   MT = 2, NW = 2, BK = 16: 128x128 tile, 256 threads, 41 KB LDS (3 workgroups / CU)    default for large problems
+//   MT = 2, NW = 2, BK = 16: 128x128 tile, 256 threads, 40 KB LDS (4 workgroups / CU)    default for large problems
 //   MT = 2, NW = 4, BK = 32: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup / CU)    knob only
 //   MT = 2, NW = 2, BK = 32: 128x128 tile, 256 threads,  72 KB LDS (2 workgroups / CU)   knob only
 //   MT = 1, NW = 2, BK = 32:  64x64  tile, 256 threads,  36 KB LDS (4 workgroups / CU)   small M (batch 1..4):
@@ -1040,14 +1040,14 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
   int choice = forced;
   if (!choice) {
-    // 128x128 tiles with a 16-deep K tile (41 KB LDS, three workgroups per CU: while one drains its stores two
+    // 128x128 tiles with a 16-deep K tile (40 KB LDS, four workgroups per CU: while one drains its stores the others
     // others keep the MFMA pipe busy; +5..11 % over the 32-deep variants at M = 65536) once there are three per CU,
     // else 64x64 tiles so that small-batch GEMMs still cover the chip
     choice = tiles(128, 128) >= 768 ? 4 : 3;
   }
   if (choice == 1) return launch_gemm_t<4, 2, 32>(g, batch, st);
   if (choice == 2) return launch_gemm_t<2, 2, 32>(g, batch, st);
-  if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 41 KB LDS: 3 workgroups / CU
+  if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 40 KB LDS: 4 workgroups / CU
   if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
   if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);
   if (choice == 8) return launch_gemm_t<2, 4, 16, 2>(g, batch, st);  // 256x128: 8 accumulator tiles per wave, 2 workgroups / CU
