@@ -1040,7 +1040,7 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
   int choice = forced;
   if (!choice) {
-    // 128x128 tiles with a 16-deep K tile (40 KB LDS, four workgroups per CU: while one drains its stores the others
+    // 128x128 tiles with a 16-deep K tile (40 KB LDS, four workgroups per CU: while one drains its stores the
     // others keep the MFMA pipe busy; +5..11 % over the 32-deep variants at M = 65536) once there are three per CU,
     // else 64x64 tiles so that small-batch GEMMs still cover the chip
     choice = tiles(128, 128) >= 768 ? 4 : 3;
