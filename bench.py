@@ -14,9 +14,12 @@ images go through one extractor call of 2*pairs images (--joint-extract 0 = two 
 Every rank processes its own `--pairs` image pairs per step (weak scaling, no data-path
 collective); one RCCL gather of per-pair records closes the job.
 
-Rank 0 prints ONE JSON line with `roofline` (dominant kernel: the fp32-MFMA stem
-convolution conv1a+conv1b+pool, timed live with HIP events around each launch inside the timed region) and
-`cpu_baseline` (the CPU oracle, a PyTorch-CPU port of the reference path, on a bounded sample).
+Rank 0 prints ONE JSON line with `roofline` (dominant kernel = the one with the largest share of the step:
+`attention_kernel<2,4>`, 18 launches per step, timed live with HIP events around each launch inside the timed
+region; `frac` = ALGORITHMIC attention FLOPs / launch time / fp32-MFMA peak, never above 1; the stem convolution
+and the split by self / cross launch are listed under `roofline.kernels`) and `cpu_baseline` (the CPU oracle, a
+PyTorch-CPU port of the reference path, on a bounded sample; also on the N > 1 line, run by rank 0 after the
+timed region and the gather).
 """
 import argparse
 import ctypes
@@ -40,23 +43,32 @@ H, W, K = 480, 640, 1024
 # algorithmic FLOPs (2*MAC) of the stem kernel per image: conv1a 1->64 and conv1b 64->64 @480x640
 # (0.35 + 22.65 GFLOP; the halo recomputation of conv1a is not counted)
 STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * 480 * 640
-PAIR_FLOPS = 182.3e9  # whole path per pair at this configuration
+PAIR_FLOPS = 182.3e9  # whole path per pair at this configuration (direct arithmetic)
+# what the matrix pipe executes per pair on the default path: 3x3 convolutions after conv1a at 4/9
+# (Winograd F(2x2,3x3)), conv1a beside the pipe, 1x1 heads and LightGlue as counted by SURVEY.md 8d with out_proj /
+# to_out folded into ffn[0] (-9 x 4 x 2*1024*256*256 = -4.83 GFLOP) and the second cross direction's sim re-evaluated
+# (+9 x 2*1024*1024*64*4 = +4.83 GFLOP): 2 x (4/9 x 50.96 + 0.79) + 78.11 = 125.0 GFLOP
+PAIR_FLOPS_EXECUTED = 2 * (4.0 / 9.0 * 50.96e9 + 0.79e9) + 78.11e9 - 4.83e9 + 4.83e9
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this same
-    command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py).  PMC counters
-    cannot be collected from inside the process, so the figure is read from profiles/; None if absent."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
-    try:
-        with open(path) as f:
-            summary = json.load(f)
-        key = next(k for k in summary if k.startswith("void conv3x3_wino_kernel<true, true")
-                   or k.startswith("conv3x3_wino_kernel<true, true"))  # the stem variant of the default path
-        return summary[key]["hbm_bytes_per_launch"]  # 64-image launches
-    except (OSError, KeyError, ValueError, StopIteration):
-        return None
+PMC_SUMMARIES = ("r03_pmc_summary.json", "r02_pmc_summary.json")  # newest first
+
+
+def pmc_traffic_bytes(kernel_prefix):
+    """(HBM bytes per launch, file) of a kernel from the committed rocprofv3 --pmc passes of this same default
+    command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py, tools/profile_r03.sh).
+    PMC counters cannot be collected from inside the process, so the figure is read from profiles/; (None, None)
+    if absent."""
+    for name in PMC_SUMMARIES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                summary = json.load(f)
+            key = next(k for k in summary if k.replace("void ", "").startswith(kernel_prefix))
+            return summary[key]["hbm_bytes_per_launch"], "profiles/" + name
+        except (OSError, KeyError, ValueError, StopIteration):
+            continue
+    return None, None
 
 
 def cpu_baseline(n_pairs: int, iters: int):
@@ -132,6 +144,36 @@ def torch_eager_same_gpu(dev, n_pairs: int = 16, iters: int = 4):
             "sample": f"{iters} iterations of {n_pairs} VGA pairs, oracle tensors on cuda:0 (PyTorch-ROCm eager fp32)"}
 
 
+def batch1_latency(dev, n_pairs: int = 24, warmup: int = 4):
+    """Information only (never `value`): the batch-1 regime of the HPatches evaluation loop (config 3: image sizes differ,
+    so pairs cannot be batched; datasets/hpatches.py:60) -- one VGA pair at a time through TwoViewPipeline on one
+    stream, device-synchronised wall clock per pair."""
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+    pipe = TwoViewPipeline({
+        "extractor": {"name": "extractors.superpoint_open", "weights": "synthetic", "max_num_keypoints": K,
+                      "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True},
+        "matcher": {"name": "matchers.lightglue", "weights": "synthetic", "filter_threshold": 0.1},
+    }).eval().to(dev)
+    v0, v1 = synthetic.synthetic_pairs(n_pairs, H, W, seed=4321, device=dev)
+    size = torch.tensor([[float(W), float(H)]], device=dev)
+    pairs = [{"view0": {"image": v0[i:i + 1], "image_size": size}, "view1": {"image": v1[i:i + 1], "image_size": size}}
+             for i in range(n_pairs)]
+    with torch.no_grad():
+        for i in range(warmup):
+            pipe(pairs[i % n_pairs])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for d in pairs:
+            pred = pipe(d)
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    return {"pairs_per_s": round(n_pairs / dt, 1), "ms_per_pair": round(dt / n_pairs * 1e3, 3), "workers": 1,
+            "mode": getattr(pipe, "batch1_mode", "sequential"),
+            "matches_last_pair": int((pred["matches0"] >= 0).sum()),
+            "sample": f"{n_pairs} VGA pairs, 1024 kpts, one at a time through TwoViewPipeline on one stream"}
+
+
 def conv_mode_of(arg):
     """The convolution arithmetic a module built with conf.conv_arithmetic = arg ends up with."""
     return arg if arg is not None else os.environ.get("GFC_CONV_MODE", "winograd")
@@ -160,8 +202,30 @@ def spawn_ranks(n: int) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL across processes)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # a rank that dies (or never reaches the rendezvous) must not leave the parent waiting for ever: poll all ranks,
+    # stop the others once one has failed, and give the whole job a deadline
+    deadline = time.monotonic() + float(os.environ.get("GFC_BENCH_TIMEOUT_S", "1500"))
+    import threading
+    out0_chunks = []
+    reader = threading.Thread(target=lambda: out0_chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        failed = any(p.poll() not in (None, 0) for p in procs)
+        if failed or time.monotonic() > deadline:
+            time.sleep(2.0 if failed else 0.0)  # let the other ranks notice and exit by themselves first
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = "".join(c for c in out0_chunks if c)
+    codes = [p.wait() for p in procs]
     for line in (out0 or "").splitlines():
         # rank 0's stdout carries the ONE JSON line; anything a backend library printed there goes to stderr
         print(line, file=sys.stdout if line.startswith("{") else sys.stderr, flush=True)
@@ -226,10 +290,13 @@ def rehearse_cpu(args):
     gathered = sharding.gather_records(sharding.pack_pair_records(pred, K))
     if rank == 0:
         allrec = torch.cat(gathered)
+        # like main(): rank 0 times the CPU baseline after the gather while the other ranks wait at the last barrier
+        base = None if args.no_cpu_baseline else cpu_baseline(args.cpu_pairs, args.cpu_iters)
         print(json.dumps({"metric": METRIC, "value": None, "unit": "image-pairs/sec", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
                           "pairs_gathered": int(allrec.shape[0]),
-                          "matches_per_rank": [int(v) for v in allrec[::b, 0].tolist()]}), flush=True)
+                          "matches_per_rank": [int(v) for v in allrec[::b, 0].tolist()],
+                          "cpu_baseline": base}), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -252,8 +319,12 @@ def main():
                          "c4 = configs[3] shape (1024x1024, 2048 kpts) for information")
     ap.add_argument("--joint-extract", type=int, default=1,
                     help="1: run the extractor once on both views' images (2*pairs images per call)")
-    ap.add_argument("--no-experimental", action="store_true",
-                    help="skip the extra `experimental_split_arithmetic` leg (profiling runs: only the default path's kernels)")
+    ap.add_argument("--experimental", action="store_true",
+                    help="also run the frozen, opt-in `experimental_split_arithmetic` leg (bf16x3-split MFMA; information "
+                         "only, never `value`); off by default")
+    ap.add_argument("--no-experimental", action="store_true", help="accepted for older scripts; the leg is off by default")
+    ap.add_argument("--no-batch1", action="store_true",
+                    help="skip the informational `batch1` leg (single-pair latency of the batch-1 evaluation regime)")
     ap.add_argument("--linear-arithmetic", default=None, choices=[None, "fp32", "split"],
                     help="LightGlue GEMMs of the timed path (see --conv-arithmetic)")
     ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split", "winograd"],
@@ -313,11 +384,14 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    calls = 1 if args.joint_extract else 2
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
-        trace = nat.KernelTrace(2 * args.steps)
+        trace = nat.KernelTrace(calls * args.steps)                     # stem launches
+        atrace = nat.KernelTrace(2 * mat.conf.n_layers * args.steps)   # attention launches (self, cross per layer)
         ext._runner.trace = trace
+        mat.trace = atrace
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
@@ -328,6 +402,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         ext._runner.trace = None
+        mat.trace = None
 
     # max over ranks
     if world > 1:
@@ -342,12 +417,14 @@ def main():
     gather_ms = (time.perf_counter() - tg) * 1e3
 
     durs = trace.durations_ms()
+    adurs = atrace.durations_ms()
     trace.close()
+    atrace.close()
 
-    # information only: the same steps with the experimental split-bf16 convolutions (opt-in arithmetic, not `value`)
+    # information only, opt-in: the same steps with the frozen experimental split-bf16 arithmetic (never `value`)
     split_info = None
-    if (world == 1 and args.conv_arithmetic is None and args.linear_arithmetic is None and args.workload == "c2"
-            and not args.no_experimental):
+    if (args.experimental and world == 1 and args.conv_arithmetic is None and args.linear_arithmetic is None
+            and args.workload == "c2"):
         try:
             ext_s = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K,
                                                 "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True,
@@ -367,22 +444,94 @@ def main():
             same = (pred_s["matches0"] >= 0).sum().item(), (pred["matches0"] >= 0).sum().item()
             split_info = {"value": round(b * args.steps / dts, 3), "unit": "image-pairs/sec",
                           "ms_per_step": round(dts / args.steps * 1e3, 3), "matches_split_vs_fp32": list(same),
-                          "note": "conv_arithmetic / linear_arithmetic / attention_arithmetic = 'split': 3x3 convolutions, "
-                                  "the LightGlue GEMMs and the attention products as six bf16 MFMA products per fp32 "
-                                  "product (three bf16 planes per operand, fp32 accumulate, fp32 soft-max).  fp32-level "
-                                  "error, whole parity suite green (GFC_CONV_MODE=split GFC_LINEAR_MODE=split "
-                                  "GFC_ATTN_MODE=split pytest -m gpu); opt-in, NOT the headline"}
+                          "note": "frozen experiment (--experimental): 3x3 convolutions, LightGlue GEMMs and attention "
+                                  "products as bf16x3-split MFMA products at fp32-level error; opt-in, NOT the headline"}
         except Exception as e:  # noqa: BLE001
             split_info = {"value": None, "error": repr(e)[:200]}
     if rank == 0:
         allrec = torch.cat(gathered)
         n_pairs_total = allrec.shape[0]
         mean_matches = float(allrec[:, 0].mean())
-        avg_ms = sum(durs) / max(len(durs), 1)
-        imgs_per_launch = 2 * b if args.joint_extract else b
-        flops_per_launch = STEM_FLOPS_PER_IMAGE * imgs_per_launch  # one stem launch per extractor call
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if durs else 0.0
         value = world * b * args.steps / elapsed
+        wino = conv_mode_of(args.conv_arithmetic) == "winograd"
+        default_shape = args.workload == "c2" and b == 32 and args.joint_extract and wino \
+            and args.linear_arithmetic is None
+
+        # ---- dominant kernel: attention (SURVEY.md 8d "attention-MFMA roofline") ------------------------------
+        # one product = Q.K^T or P.V of one problem over its 4 heads: 2 * K * K * 64 * 4 FLOP
+        prod = 2.0 * K * K * 64 * 4
+        self_alg = 2 * b * 2 * prod          # 2b images, QK^T + PV each
+        cross_alg = b * 3 * prod             # b pairs: ONE sim + two PV products (lightglue.py:207-217)
+        cross_exec = b * 4 * prod            # the kernel evaluates the second direction's sim again
+        self_ms, cross_ms = adurs[0::2], adurs[1::2]
+        n_self, n_cross = len(self_ms), len(cross_ms)
+        att_ms = sum(adurs)
+        att_alg = n_self * self_alg + n_cross * cross_alg
+        att_exec = n_self * self_alg + n_cross * cross_exec
+
+        def tflops(flops, ms):
+            return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+
+        att_kernel = ("attention_kernel<2, 4>" if 2 * b * 4 * ((K + 255) // 256) >= 1024 else "attention_kernel<1, 4>")
+        if args.linear_arithmetic == "split":
+            att_kernel = "attention_split_kernel (experimental split arithmetic)"
+        att_traffic, att_src = pmc_traffic_bytes("attention_kernel<2, 4>") if default_shape else (None, None)
+        ach = tflops(att_alg, att_ms)
+        roof = {"bound": "mfma",
+                "kernel": att_kernel + " (flash-style self / bidirectional cross attention, fp32 MFMA 32x32x2; the "
+                          "kernel with the largest share of the step)",
+                "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                "executed_tflops": round(tflops(att_exec, att_ms), 2),
+                "executed_frac": round(tflops(att_exec, att_ms) / FP32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": att_traffic,
+                "traffic_note": ("HBM bytes/launch (mean of self and cross launches), rocprofv3 --pmc FETCH_SIZE(x2) + "
+                                 f"WRITE_SIZE passes of the default command ({att_src}); algorithmic per launch: Q, K, V "
+                                 f"read once + O written = {2 * b * K * 256 * 4 * 4 / 1e6:.1f} MB"),
+                "launches_timed": len(adurs),
+                "avg_launch_ms": round(att_ms / max(len(adurs), 1), 4),
+                "flops_per_launch": round(att_alg / max(len(adurs), 1)),
+                "share_of_step": round(att_ms / (elapsed * 1e3), 4),
+                "definition": "achieved = ALGORITHMIC attention FLOPs (QK^T + PV; cross attention counted with ONE "
+                              "shared sim) summed over the timed launches / their summed HIP-event durations; "
+                              "executed_* counts the cross sim twice, as the kernel evaluates it"}
+
+        # ---- the other traced kernels ---------------------------------------------------------------------------
+        kernels = [
+            {"kernel": att_kernel + " [self launches]", "launches_timed": n_self,
+             "avg_launch_ms": round(sum(self_ms) / max(n_self, 1), 4), "flops_per_launch": round(self_alg),
+             "achieved": round(tflops(n_self * self_alg, sum(self_ms)), 2),
+             "frac": round(tflops(n_self * self_alg, sum(self_ms)) / FP32_MFMA_PEAK_TFLOPS, 4)},
+            {"kernel": att_kernel + " [cross launches]", "launches_timed": n_cross,
+             "avg_launch_ms": round(sum(cross_ms) / max(n_cross, 1), 4), "flops_per_launch": round(cross_alg),
+             "achieved": round(tflops(n_cross * cross_alg, sum(cross_ms)), 2),
+             "frac": round(tflops(n_cross * cross_alg, sum(cross_ms)) / FP32_MFMA_PEAK_TFLOPS, 4),
+             "executed_frac": round(tflops(n_cross * cross_exec, sum(cross_ms)) / FP32_MFMA_PEAK_TFLOPS, 4)},
+        ]
+        stem_ms = sum(durs)
+        imgs_per_launch = 2 * b if args.joint_extract else b
+        stem_alg = STEM_FLOPS_PER_IMAGE * imgs_per_launch  # direct-convolution FLOPs of SURVEY.md 8d
+        # Winograd F(2x2,3x3): 16 instead of 36 multiplications per 2x2 output block and input channel, so the matrix
+        # pipe executes 4/9 of conv1b's direct FLOPs (conv1a, cin = 1, runs beside it)
+        stem_exec = (2 * 4 * 64 * 64 * H * W * imgs_per_launch) if wino else stem_alg
+        stem_traffic, stem_src = pmc_traffic_bytes("conv3x3_wino_kernel<true, true") if default_shape else (None, None)
+        kernels.append(
+            {"kernel": stem_kernel_name(args.conv_arithmetic), "launches_timed": len(durs),
+             "avg_launch_ms": round(stem_ms / max(len(durs), 1), 4),
+             "executed_flops_per_launch": stem_exec,
+             "achieved": round(tflops(len(durs) * stem_exec, stem_ms), 2),
+             "frac": round(tflops(len(durs) * stem_exec, stem_ms) / FP32_MFMA_PEAK_TFLOPS, 4),
+             "algorithmic_equiv_tflops": round(tflops(len(durs) * stem_alg, stem_ms), 2),
+             "share_of_step": round(stem_ms / (elapsed * 1e3), 4),
+             "traffic": stem_traffic,
+             "note": "frac = FLOPs the matrix pipe EXECUTES / peak; algorithmic_equiv_tflops = direct-convolution FLOPs "
+                     "(SURVEY.md 8d) / time: a Winograd kernel may exceed the pipe's peak in that unit, it is not a "
+                     f"roofline fraction; traffic from {stem_src}, algorithmic "
+                     f"{imgs_per_launch * H * W * 4 / 1e6:.1f} MB in + "
+                     f"{imgs_per_launch * (H // 2) * (W // 2) * 64 * 4 / 1e6:.1f} MB out"})
+        roof["kernels"] = kernels
+
+        exec_pair_flops = PAIR_FLOPS_EXECUTED if args.workload == "c2" and wino else None
         out = {
             "metric": METRIC if args.workload == "c2" else "image-pairs/sec (SuperPoint+LightGlue, 2048 kpts, 1024x1024)",
             "value": round(value, 3),
@@ -404,33 +553,18 @@ def main():
                        "global_pairs_per_step": b * world, "keypoints": K, "image": [H, W],
                        "parallelism": f"dp{world} (pairs sharded, one final gather)",
                        "weights": "name-seeded seed 0 (no network)", "mean_matches_per_pair": round(mean_matches, 1),
-                       "pairs_gathered": n_pairs_total, "extractor_calls_per_step": 1 if args.joint_extract else 2, "final_gather_ms": round(gather_ms, 3),
+                       "pairs_gathered": n_pairs_total, "extractor_calls_per_step": calls,
+                       "final_gather_ms": round(gather_ms, 3),
                        "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                       "pipeline_tflops": round(value / world * PAIR_FLOPS / 1e12, 2)},
-            "roofline": {"bound": "mfma", "kernel": stem_kernel_name(args.conv_arithmetic),
-                         "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         # the committed PMC passes are of the default command; other shapes: not measured
-                         "traffic": pmc_traffic_bytes() if (args.workload == "c2" and imgs_per_launch == 64
-                                                            and conv_mode_of(args.conv_arithmetic) == "winograd") else None,
-                         "traffic_note": "HBM bytes/launch, rocprofv3 --pmc FETCH_SIZE(x2)+WRITE_SIZE passes of the "
-                                         "default command (profiles/r02_pmc_summary.json); algorithmic per launch: "
-                                         f"{imgs_per_launch * H * W * 4 / 1e6:.1f} MB image in + "
-                                         f"{imgs_per_launch * (H // 2) * (W // 2) * 64 * 4 / 1e6:.1f} MB pooled "
-                                         "activation out",
-                         "launches_timed": len(durs), "avg_launch_ms": round(avg_ms, 4),
-                         "flops_per_launch": flops_per_launch},
+                       # whole path per GPU: direct-arithmetic FLOPs of SURVEY.md 8d (a Winograd / folded implementation
+                       # executes fewer), and the FLOPs the matrix pipe really executes
+                       "pipeline_algorithmic_tflops": round(value / world * PAIR_FLOPS / 1e12, 2),
+                       "pipeline_executed_tflops": (round(value / world * exec_pair_flops / 1e12, 2)
+                                                    if exec_pair_flops else None),
+                       "pipeline_executed_frac": (round(value / world * exec_pair_flops / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4)
+                                                  if exec_pair_flops else None)},
+            "roofline": roof,
         }
-        if conv_mode_of(args.conv_arithmetic) == "winograd":
-            # `achieved` above is ALGORITHMIC (direct-convolution FLOPs of SURVEY.md 8d / launch time), as the contract
-            # defines it; the Winograd kernel issues 16 instead of 36 multiplications per 2x2 output block and cin, so
-            # the matrix pipe executes 4/9 of conv1b's algorithmic FLOPs (conv1a runs on the VALU).
-            executed = 2 * 4 * 64 * 64 * H * W * imgs_per_launch
-            mfma_tf = executed / (avg_ms * 1e-3) / 1e12 if durs else 0.0
-            out["roofline"]["mfma_executed_tflops"] = round(mfma_tf, 2)
-            out["roofline"]["mfma_frac"] = round(mfma_tf / FP32_MFMA_PEAK_TFLOPS, 4)
-            out["roofline"]["note"] = ("Winograd F(2x2,3x3) on fp32 MFMA: frac = algorithmic FLOPs / peak may exceed 1; "
-                                       "mfma_frac = FLOPs the matrix pipe actually executes / peak")
         try:  # what the matrix pipe of THIS box sustains (the data-sheet 157.3 TFLOP/s assumes 2.4 GHz): context only
             tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
             nat.check(nat.lib().gfc_probe_mfma_peak(80000, ctypes.byref(tf), ctypes.byref(ghz), nat.stream_ptr(dev)), "probe")
@@ -442,16 +576,22 @@ def main():
         if split_info is not None:
             out["experimental_split_arithmetic"] = split_info
         if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":
-            out["dtype"] = "f32 via 3 x bf16 split MFMA in the 3x3 convolutions (experimental), f32 elsewhere"
-            out["roofline"]["note"] = "split arithmetic: the stem is not an fp32-MFMA kernel; frac is fp32-equivalent FLOPs / fp32 peak"
+            out["dtype"] = "f32 via 3 x bf16 split MFMA (experimental), f32 elsewhere"
+            out["roofline"]["note"] = "split arithmetic: not fp32-MFMA kernels; frac is fp32-equivalent FLOPs / fp32 peak"
         if args.workload == "c2" and not args.no_self_check:
             try:
                 out["self_check"] = self_check(v0, v1, p0, p1, pred)
             except Exception as e:  # noqa: BLE001
                 out["self_check"] = {"pairs_equal": None, "error": repr(e)[:200]}
-        if not args.no_cpu_baseline and world == 1:
+        if args.workload == "c2" and not args.no_batch1:
+            try:  # information only: the batch-1 regime of the HPatches evaluation loop (never `value`)
+                out["batch1"] = batch1_latency(dev)
+            except Exception as e:  # noqa: BLE001
+                out["batch1"] = {"pairs_per_s": None, "error": repr(e)[:200]}
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region and the gather; at N > 1 the other ranks wait at the closing barrier
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)
-            if args.workload == "c2":
+            if args.workload == "c2" and world == 1:
                 try:  # context only: never let the comparison leg cost the measurement line
                     out["cpu_baseline"]["same_gpu_torch_eager"] = torch_eager_same_gpu(dev)
                 except Exception as e:  # noqa: BLE001

@@ -102,11 +102,18 @@ def lib():
         "H5Oopen": (hid_t, [hid_t, c_char_p, hid_t]),
         "H5Oclose": (herr_t, [hid_t]),
         "H5Iget_type": (c_int, [hid_t]),
-        "H5Ovisit": (herr_t, [hid_t, c_int, c_int, c_void_p, c_void_p]),
     }
-    for name, (res, args) in proto.items():
-        fn = getattr(h, name)
-        fn.restype, fn.argtypes = res, args
+    try:
+        for name, (res, args) in proto.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        # HDF5 1.10 exports the un-versioned H5Ovisit; 1.12 and later only H5Ovisit1 / 2 / 3.  H5Ovisit1 has the 1.10
+        # signature (the callback's info struct differs between versions, it is not read here).
+        visit = getattr(h, "H5Ovisit1", None) or getattr(h, "H5Ovisit")
+        visit.restype, visit.argtypes = herr_t, [hid_t, c_int, c_int, c_void_p, c_void_p]
+        h.gfc_visit = visit
+    except AttributeError as e:  # a library without one of the entry points: treated like no library at all
+        raise Hdf5Unavailable(f"{path}: {e}") from e
     if h.H5open() < 0:
         raise Hdf5Unavailable("H5open failed")
     h.H5Eset_auto2(0, None, None)  # no error-stack printing: failures are reported through return codes below
@@ -114,7 +121,10 @@ def lib():
                      ("i8", "H5T_NATIVE_INT64_g"), ("u1", "H5T_NATIVE_UINT8_g"), ("i1", "H5T_NATIVE_INT8_g"),
                      ("u4", "H5T_NATIVE_UINT32_g"), ("u8", "H5T_NATIVE_UINT64_g"), ("i2", "H5T_NATIVE_INT16_g"),
                      ("u2", "H5T_NATIVE_UINT16_g"), ("f4le", "H5T_IEEE_F32LE_g"), ("lcpl", "H5P_CLS_LINK_CREATE_ID_g")):
-        _native[key] = hid_t.in_dll(h, sym).value
+        try:
+            _native[key] = hid_t.in_dll(h, sym).value
+        except ValueError as e:  # symbol not exported by this build of the library
+            raise Hdf5Unavailable(f"{path}: {e}") from e
     # IEEE binary16, the way h5py builds it: a 2-byte copy of F32LE with the half-precision bit fields
     f2 = h.H5Tcopy(_native["f4le"])
     ok = h.H5Tset_fields(f2, 15, 10, 5, 0, 10) >= 0 and h.H5Tset_size(f2, 2) >= 0 and h.H5Tset_ebias(f2, 15) >= 0
@@ -193,7 +203,7 @@ def read_records(path) -> dict:
     cb = _VISIT(visit)
     out = {}
     try:
-        _chk(h.H5Ovisit(f, H5_INDEX_NAME, H5_ITER_INC, ctypes.cast(cb, c_void_p), None), "H5Ovisit")
+        _chk(h.gfc_visit(f, H5_INDEX_NAME, H5_ITER_INC, ctypes.cast(cb, c_void_p), None), "H5Ovisit")
         for full in names:
             if full == "." or "/" not in full:
                 continue

@@ -126,6 +126,9 @@ SIGNATURES = {
     "gfc_lg_assign_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_lg_assign": (c_int, [POINTER(LgParams), c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float]
                       + [c_void_p] * 6 + [c_size_t, c_void_p]),
+    "gfc_lg_packed_workspace_bytes": (c_size_t, [c_int] * 3),
+    "gfc_lg_forward_packed": (c_int, [POINTER(LgParams)] + [c_void_p] * 5 + [c_int] * 3 + [c_float] + [c_void_p] * 7
+                              + [c_size_t, POINTER(Trace), c_void_p]),
     "gfc_lg_forward": (c_int, [POINTER(LgParams)] + [c_void_p] * 8 + [c_int] * 3 + [c_float] + [c_void_p] * 8
                        + [c_size_t, c_void_p]),
 }

@@ -135,27 +135,6 @@ def pad_keypoints_native(kpts, scores, counts, k, low, data, image):
     return kpts[:, :k].contiguous(), scores[:, :k].contiguous()
 
 
-def pad_random_c(kpts, scores, counts, k, low, high):
-    """`pad_and_stack(..., mode="random_c")` + zeros for the scores, on the device and without a
-    host synchronisation (gluefactory/models/utils/misc.py:19-62,103-113): slots >= count are
-    filled with per-column uniform samples in [min, max] of the image's own key points (bounds
-    [low, high] when the image has none).  The random stream is torch's device generator, so the
-    padded values themselves differ from the reference's CPU generator (they are random there too)."""
-    b, cap, _ = kpts.shape
-    idx = torch.arange(cap, device=kpts.device)[None, :, None]
-    valid = idx < counts[:, None, None]
-    big = torch.finfo(kpts.dtype).max
-    mn = torch.where(valid, kpts, kpts.new_full((), big)).amin(1, keepdim=True)
-    mx = torch.where(valid, kpts, kpts.new_full((), -big)).amax(1, keepdim=True)
-    empty = (counts == 0)[:, None, None]
-    mn = torch.where(empty, torch.as_tensor(low, device=kpts.device, dtype=kpts.dtype), mn)
-    mx = torch.where(empty, torch.as_tensor(high, device=kpts.device, dtype=kpts.dtype), mx)
-    fill = torch.rand((b, cap, 2), device=kpts.device, dtype=kpts.dtype) * (mx - mn) + mn
-    kpts = torch.where(valid, kpts, fill)
-    scores = torch.where(valid[..., 0], scores, scores.new_zeros(()))
-    return kpts[:, :k].contiguous(), scores[:, :k].contiguous()
-
-
 class SuperPointRunner:
     """Launch sequence for one extractor call."""
 

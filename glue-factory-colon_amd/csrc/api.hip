@@ -14,7 +14,11 @@ int gfc_assign_filter_fused(float* scores, const float* z0, const float* z1, int
                             int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* stats, void* tail,
                             hipStream_t st);
 
-extern "C" const char* gfc_version(void) { return "gfc_amd 0.1.0 (gfx950, fp32 MFMA)"; }
+// GFC_SOURCE_HASH: content hash of the whole source set, passed by csrc/build.py when it compiles this unit
+#ifndef GFC_SOURCE_HASH
+#define GFC_SOURCE_HASH "unknown"
+#endif
+extern "C" const char* gfc_version(void) { return "gfc_amd 0.3.0 (gfx950, fp32 MFMA) src " GFC_SOURCE_HASH; }
 
 #define GFC_TRY(expr)            \
   do {                           \
@@ -118,7 +122,19 @@ extern "C" int gfc_probe_mfma_peak(int mfmas_per_wave, float* tflops, float* sha
   return GFC_OK;
 }
 
-// stem (conv1a + conv1b + pool, the dominant kernel of the path) with optional event bracket
+// optional event bracket around one launch (gfc_trace, include/gfc_amd.h)
+static inline bool trace_begin(gfc_trace* tr, hipStream_t st) {
+  const bool rec = tr && tr->start && tr->stop && tr->count < tr->capacity;
+  if (rec) (void)hipEventRecord((hipEvent_t)tr->start[tr->count], st);
+  return rec;
+}
+static inline void trace_end(gfc_trace* tr, hipStream_t st, bool rec) {
+  if (!rec) return;
+  (void)hipEventRecord((hipEvent_t)tr->stop[tr->count], st);
+  tr->count++;
+}
+
+// stem (conv1a + conv1b + pool) with optional event bracket
 static int traced_stem(gfc_trace* tr, hipStream_t st, const gfc_sp_params* p, const float* x, float* y, int B, int H,
                        int W) {
   const bool rec = tr && tr->start && tr->stop && tr->count < tr->capacity;
@@ -218,18 +234,19 @@ struct LgPlan {
 extern "C" size_t gfc_lg_layer_workspace_bytes(int rows);
 extern "C" size_t gfc_lg_assign_workspace_bytes(int B, int M, int N);
 
-static LgPlan lg_plan(int B, int M, int N) {
+// packed = the caller owns the row buffer x and hands over packed key points (gfc_lg_forward_packed): no x / msg slots
+static LgPlan lg_plan(int B, int M, int N, bool packed = false) {
   LgPlan p;
   p.R = (size_t)B * (M + N);
   size_t off = 0;
   auto take = [&](size_t bytes) { size_t o = off; off += gfc_align(bytes); return o; };
-  p.x = take(p.R * 256 * 4);
+  p.x = packed ? 0 : take(p.R * 256 * 4);
   // stage scratch: one layer's workspace, re-used by the assignment head afterwards
   size_t stage = gfc_lg_layer_workspace_bytes((int)p.R);
   const size_t asg = gfc_lg_assign_workspace_bytes(B, M, N);
   if (asg > stage) stage = asg;
   p.qkv = take(stage);
-  p.msg = take(p.R * 4 * 4);  // packed key points [R][2] (+ scales / orientations [R][2]) for the rotary tables
+  p.msg = packed ? 0 : take(p.R * 4 * 4);  // packed key points [R][2] (+ scales / orientations [R][2]) for the rotary tables
   p.cosb = take(p.R * 64 * 4);
   p.sinb = take(p.R * 64 * 4);
   p.csb = take(p.R * 64 * 4);  // the same values packed (cos, sin) per frequency: what the QKV epilogue reads
@@ -241,6 +258,10 @@ static LgPlan lg_plan(int B, int M, int N) {
 extern "C" size_t gfc_lg_workspace_bytes(int B, int M, int N) {
   if (B <= 0 || M <= 0 || N <= 0) return 0;
   return lg_plan(B, M, N).total;
+}
+extern "C" size_t gfc_lg_packed_workspace_bytes(int B, int M, int N) {
+  if (B <= 0 || M <= 0 || N <= 0) return 0;
+  return lg_plan(B, M, N, true).total;
 }
 
 // tables: self problems [2B][4], cross problems [2B][4], row0 [2B], n [2B], sizes [2B][2]
@@ -279,7 +300,7 @@ extern "C" size_t gfc_lg_layer_workspace_bytes(int rows) {
 
 static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, const float* csb,
                          int R, const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
-                         size_t ws_bytes, void* stream);
+                         size_t ws_bytes, void* stream, const float* x_in = nullptr, gfc_trace* tr = nullptr);
 
 extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, int R,
                             const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
@@ -288,9 +309,12 @@ extern "C" int gfc_lg_layer(const gfc_lg_params* p, int l, float* x, const float
 }
 
 // csb (optional): the rotary table packed for the QKV epilogue (one float4 per four channels instead of two)
+// x_in (optional): the rows the SELF block reads (QKV operand, first half of the ffn[0] operand, residual); its result
+// and everything after it live in x.  gfc_lg_forward_packed passes the caller's descriptors for layer 0, so that they
+// are never copied into the row buffer.  tr (optional): event pairs around the two attention launches.
 static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* cosb, const float* sinb, const float* csb,
                          int R, const int32_t* self_p, const int32_t* cross_p, int n_problems, int maxn, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         size_t ws_bytes, void* stream, const float* x_in, gfc_trace* tr) {
   if (!p || !x || !cosb || !sinb || !self_p || !cross_p || !ws || R <= 0 || n_problems <= 0 || maxn <= 0)
     return GFC_ERR_INVALID;
   if (l < 0 || l >= p->n_layers) return GFC_ERR_INVALID;
@@ -313,8 +337,13 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
   // attention: fp32 MFMA (default; with its key split for small problem sets) or the experimental split arithmetic
   const bool att_split = p->attention_mode == 1 && (long long)n_problems * 4 * ((maxn + 127) / 128) >= 512;
   auto attn = [&](const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* probs) -> int {
-    if (att_split) return gfc_attention_split(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, st);
-    return gfc_attention(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, att_ws, att_ws_bytes, st);
+    const bool rec = trace_begin(tr, st);
+    const int s = att_split
+                      ? gfc_attention_split(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, st)
+                      : gfc_attention(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, att_ws,
+                                      att_ws_bytes, st);
+    trace_end(tr, st, rec);
+    return s;
   };
   auto lin = [&](const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w, const void* wsp,
                  int ldw, const float* bias, const float* resid, const float* rc, const float* rs, int rot_cols, float* y,
@@ -328,19 +357,20 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
   // ffn[0] -> LayerNorm -> GELU (lightglue.py:143-148) into hbuf: one row-owning kernel once there are enough
   // 128-row tiles to cover the chip (>= 128: batch >= 8 pairs of 1024 points), else GEMM + in-place LayerNorm pass
   const bool ffn_fused = !split && (gfc_knobs().ffn_fused >= 0 ? gfc_knobs().ffn_fused != 0 : R >= 128 * 128);  // knob: 0 off, 1 / 2 tile variants
-  auto ffn01 = [&](const float* a1, const float* w0, const void* w0_split, const float* b0, const float* ln_g,
-                   const float* ln_b) -> int {
-    if (ffn_fused) return gfc_linear_layernorm_gelu(x, D, D, a1, D, D, w0, 512, b0, ln_g, ln_b, hbuf, 512, R, 512, st);
-    GFC_TRY(lin(x, D, D, a1, D, D, w0, w0_split, 512, b0, nullptr, nullptr, nullptr, 0, hbuf, 512, 512));
+  auto ffn01 = [&](const float* a0, const float* a1, const float* w0, const void* w0_split, const float* b0,
+                   const float* ln_g, const float* ln_b) -> int {
+    if (ffn_fused) return gfc_linear_layernorm_gelu(a0, D, D, a1, D, D, w0, 512, b0, ln_g, ln_b, hbuf, 512, R, 512, st);
+    GFC_TRY(lin(a0, D, D, a1, D, D, w0, w0_split, 512, b0, nullptr, nullptr, nullptr, 0, hbuf, 512, 512));
     return gfc_layernorm_gelu(hbuf, 512, R, 512, ln_g, ln_b, st);
   };
+  const float* xs = x_in ? x_in : x;  // what the self block reads
   {
 
     // ---- self block (lightglue.py:151-164) ----
     if (csb && !split)
-      GFC_TRY(gfc_linear_rot_packed(x, D, D, p->wqkv[l], D, p->bqkv[l], csb, 512, qkv, 768, R, 768, st));
+      GFC_TRY(gfc_linear_rot_packed(xs, D, D, p->wqkv[l], D, p->bqkv[l], csb, 512, qkv, 768, R, 768, st));
     else
-      GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
+      GFC_TRY(lin(xs, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
                   768));
     GFC_TRY(attn(qkv, 768, qkv + 256, 768, qkv + 512, 768, self_p));
     // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
@@ -351,8 +381,8 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1s = msg;
     }
-    GFC_TRY(ffn01(a1s, p->s_ffn0_w[l], p->s_ffn0_split[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l]));
-    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], p->s_ffn3_split[l], 512, p->s_ffn3_b[l], x, nullptr, nullptr,
+    GFC_TRY(ffn01(xs, a1s, p->s_ffn0_w[l], p->s_ffn0_split[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l]));
+    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], p->s_ffn3_split[l], 512, p->s_ffn3_b[l], xs, nullptr, nullptr,
                 0, x, D, D));
     // ---- cross block (lightglue.py:193-222) ----
     GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], p->c_qkv_split[l], D, p->c_qkv_b[l], nullptr, nullptr, nullptr, 0,
@@ -364,7 +394,7 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1c = msg;
     }
-    GFC_TRY(ffn01(a1c, p->c_ffn0_w[l], p->c_ffn0_split[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l]));
+    GFC_TRY(ffn01(x, a1c, p->c_ffn0_w[l], p->c_ffn0_split[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l]));
     GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], p->c_ffn3_split[l], 512, p->c_ffn3_b[l], x, nullptr, nullptr,
                 0, x, D, D));
     }
@@ -430,6 +460,70 @@ extern "C" int gfc_lg_assign(const gfc_lg_params* p, int l, const float* x0, con
   return GFC_OK;
 }
 
+// Common body.  kp [R,2] / so [R,2] (nullable) / desc [R,Din]: rows of side 0 first, then side 1 (packed).
+// x [R,256]: the row buffer every layer updates in place; it ends up holding the last layer's descriptors.
+static int lg_forward_core(const gfc_lg_params* p, const float* kp, const float* so, const float* desc, const float* size0,
+                           const float* size1, int B, int M, int N, float threshold, int64_t* m0, int64_t* m1, float* ms0,
+                           float* ms1, float* log_assignment, float* x, char* base, const LgPlan& pl, gfc_trace* tr,
+                           hipStream_t st) {
+  float* cosb = (float*)(base + pl.cosb);
+  float* sinb = (float*)(base + pl.sinb);
+  float* csb = (float*)(base + pl.csb);
+  int* self_p = (int*)(base + pl.tables);
+  int* cross_p = self_p + 8 * B;
+  int* row0 = cross_p + 8 * B;
+  int* nrow = row0 + 2 * B;
+  float* sizes = (float*)(nrow + 2 * B);
+  const int R = (int)pl.R, R0 = B * M;
+  const int D = 256;
+  const int pdim = p->posenc_dim == 0 ? 2 : p->posenc_dim;
+
+  hipLaunchKernelGGL(lg_tables_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, M, N, size0, size1, self_p, cross_p,
+                     row0, nrow, sizes);
+  GFC_LAUNCH_CHECK();
+  GFC_TRY(gfc_lg_posenc_packed(kp, so, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, pdim, cosb, sinb, csb, st));
+
+  // descriptors -> rows.  input_dim == 256: layer 0's self block reads them where they are (no copy);
+  // otherwise input_proj writes the rows (lightglue.py:352-355,464-465)
+  const float* x_in = desc;
+  if (p->input_dim != D) {
+    const int Din = p->input_dim;
+    GFC_TRY(gfc_linear(desc, Din, Din, nullptr, 0, 0, p->input_proj_w, Din, p->input_proj_b, nullptr, nullptr, 1.f,
+                       nullptr, nullptr, nullptr, 0, x, D, R, D, st));
+    x_in = nullptr;
+  }
+  const int maxn = M > N ? M : N;
+  for (int l = 0; l < p->n_layers; ++l)
+    GFC_TRY(lg_layer_impl(p, l, x, cosb, sinb, csb, R, self_p, cross_p, 2 * B, maxn, base + pl.qkv,
+                          gfc_lg_layer_workspace_bytes(R), st, l == 0 ? x_in : nullptr, tr));
+
+  // ---- assignment (lightglue.py:279-288) + filter (lightglue.py:294-319) ----
+  return gfc_lg_assign(p, p->n_layers - 1, x, x + (size_t)R0 * D, B, M, N, threshold, m0, m1, ms0, ms1, log_assignment,
+                       base + pl.qkv, gfc_lg_assign_workspace_bytes(B, M, N), st);
+}
+
+static int lg_forward_args_ok(const gfc_lg_params* p, int B, int M, int N, bool has_so) {
+  if (B <= 0 || M <= 0 || N <= 0 || p->n_layers <= 0 || p->n_layers > GFC_LG_MAX_LAYERS) return 0;
+  if (p->input_dim != 256 && (!p->input_proj_w || !p->input_proj_b || p->input_dim % 32)) return 0;
+  const int pdim = p->posenc_dim == 0 ? 2 : p->posenc_dim;
+  if ((pdim != 2 && pdim != 4) || ((pdim == 4) != has_so)) return 0;
+  return 1;
+}
+
+extern "C" int gfc_lg_forward_packed(const gfc_lg_params* p, const float* kpts, const float* desc, const float* size0,
+                                     const float* size1, const float* scale_ori, int B, int M, int N, float threshold,
+                                     int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment, float* rows,
+                                     void* ws, size_t ws_bytes, gfc_trace* attention_trace, void* stream) {
+  if (!p || !kpts || !desc || !size0 || !size1 || !m0 || !m1 || !ms0 || !ms1 || !log_assignment || !rows || !ws)
+    return GFC_ERR_INVALID;
+  if (!lg_forward_args_ok(p, B, M, N, scale_ori != nullptr)) return GFC_ERR_INVALID;
+  if (rows == desc) return GFC_ERR_INVALID;  // the caller's descriptors are read-only
+  if (ws_bytes < gfc_lg_packed_workspace_bytes(B, M, N)) return GFC_ERR_WORKSPACE;
+  const LgPlan pl = lg_plan(B, M, N, true);
+  return lg_forward_core(p, kpts, scale_ori, desc, size0, size1, B, M, N, threshold, m0, m1, ms0, ms1, log_assignment,
+                         rows, (char*)ws, pl, attention_trace, (hipStream_t)stream);
+}
+
 extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,
                               const float* desc1, const float* size0, const float* size1,
                               const float* scale_ori0, const float* scale_ori1, int B, int M, int N,
@@ -439,70 +533,41 @@ extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const 
   if (!p || !kpts0 || !kpts1 || !desc0 || !desc1 || !size0 || !size1 || !m0 || !m1 || !ms0 || !ms1 ||
       !log_assignment || !ws)
     return GFC_ERR_INVALID;
-  if (B <= 0 || M <= 0 || N <= 0 || p->n_layers <= 0 || p->n_layers > GFC_LG_MAX_LAYERS) return GFC_ERR_INVALID;
-  if (p->input_dim != 256 && (!p->input_proj_w || !p->input_proj_b || p->input_dim % 32)) return GFC_ERR_INVALID;
-  const int pdim = p->posenc_dim == 0 ? 2 : p->posenc_dim;
-  if ((pdim != 2 && pdim != 4) || ((pdim == 4) != (scale_ori0 != nullptr && scale_ori1 != nullptr))) return GFC_ERR_INVALID;
+  if (!lg_forward_args_ok(p, B, M, N, scale_ori0 != nullptr && scale_ori1 != nullptr)) return GFC_ERR_INVALID;
+  if ((scale_ori0 != nullptr) != (scale_ori1 != nullptr)) return GFC_ERR_INVALID;
   if (ws_bytes < gfc_lg_workspace_bytes(B, M, N)) return GFC_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const LgPlan pl = lg_plan(B, M, N);
   char* base = (char*)ws;
   float* x = (float*)(base + pl.x);
   float* msg = (float*)(base + pl.msg);
-  float* cosb = (float*)(base + pl.cosb);
-  float* sinb = (float*)(base + pl.sinb);
-  int* self_p = (int*)(base + pl.tables);
-  int* cross_p = self_p + 8 * B;
-  int* row0 = cross_p + 8 * B;
-  int* nrow = row0 + 2 * B;
-  float* sizes = (float*)(nrow + 2 * B);
-  const int R = (int)pl.R, R0 = B * M, R1 = B * N;
-  const int D = 256;
-
-  hipLaunchKernelGGL(lg_tables_kernel, dim3((B + 63) / 64), dim3(64), 0, st, B, M, N, size0, size1, self_p, cross_p,
-                     row0, nrow, sizes);
-  GFC_LAUNCH_CHECK();
-
-  // keypoints of both sides packed after each other for the rotary tables
-  // (reuse msg as scratch: [R][2] floats)
-  if (hipMemcpyAsync(msg, kpts0, (size_t)R0 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
-  if (hipMemcpyAsync(msg + (size_t)R0 * 2, kpts1, (size_t)R1 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return GFC_ERR_LAUNCH;
+  const int R0 = B * M, R1 = B * N;
+  const size_t R = pl.R;
+  const int Din = p->input_dim;
+  auto d2d = [&](void* dst, const void* src, size_t bytes) {
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st) == hipSuccess;
+  };
+  // the two sides arrive as separate arrays: pack key points (and scales / orientations) behind each other
+  if (!d2d(msg, kpts0, (size_t)R0 * 2 * 4) || !d2d(msg + (size_t)R0 * 2, kpts1, (size_t)R1 * 2 * 4)) return GFC_ERR_LAUNCH;
   float* so = nullptr;
-  if (pdim == 4) {  // scale / orientation of both sides packed the same way, behind the key points
-    so = msg + (size_t)R * 2;
-    if (hipMemcpyAsync(so, scale_ori0, (size_t)R0 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
-    if (hipMemcpyAsync(so + (size_t)R0 * 2, scale_ori1, (size_t)R1 * 2 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+  if (scale_ori0) {
+    so = msg + R * 2;
+    if (!d2d(so, scale_ori0, (size_t)R0 * 2 * 4) || !d2d(so + (size_t)R0 * 2, scale_ori1, (size_t)R1 * 2 * 4))
       return GFC_ERR_LAUNCH;
   }
-  float* csb = (float*)(base + pl.csb);
-  GFC_TRY(gfc_lg_posenc_packed(msg, so, sizes, row0, nrow, 2 * B, M > N ? M : N, p->posenc_wr, pdim, cosb, sinb, csb, st));
-
-  // descriptors -> x (input_proj when input_dim != 256, lightglue.py:352-355,464-465)
-  if (p->input_dim == D) {
-    if (hipMemcpyAsync(x, desc0, (size_t)R0 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return GFC_ERR_LAUNCH;
-    if (hipMemcpyAsync(x + (size_t)R0 * D, desc1, (size_t)R1 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+  // descriptors: packed into the row buffer (input_dim == 256), or -- when the two arrays happen to be adjacent in
+  // memory -- read in place; with an input projection the packed copy lives in the (not yet used) layer scratch
+  const float* desc = desc0;
+  if (desc1 != desc0 + (size_t)R0 * Din) {
+    float* stage = Din == 256 ? x : (float*)(base + pl.qkv);
+    if (!d2d(stage, desc0, (size_t)R0 * Din * 4) || !d2d(stage + (size_t)R0 * Din, desc1, (size_t)R1 * Din * 4))
       return GFC_ERR_LAUNCH;
-  } else {
-    const int Din = p->input_dim;
-    GFC_TRY(gfc_linear(desc0, Din, Din, nullptr, 0, 0, p->input_proj_w, Din, p->input_proj_b, nullptr, nullptr, 1.f,
-                       nullptr, nullptr, nullptr, 0, x, D, R0, D, st));
-    GFC_TRY(gfc_linear(desc1, Din, Din, nullptr, 0, 0, p->input_proj_w, Din, p->input_proj_b, nullptr, nullptr, 1.f,
-                       nullptr, nullptr, nullptr, 0, x + (size_t)R0 * D, D, R1, D, st));
+    desc = stage;
   }
-
-  const int maxn = M > N ? M : N;
-  for (int l = 0; l < p->n_layers; ++l)
-    GFC_TRY(lg_layer_impl(p, l, x, cosb, sinb, csb, R, self_p, cross_p, 2 * B, maxn, base + pl.qkv,
-                          gfc_lg_layer_workspace_bytes(R), st));
-
-  if (ref_desc0 && hipMemcpyAsync(ref_desc0, x, (size_t)R0 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return GFC_ERR_LAUNCH;
-  if (ref_desc1 &&
-      hipMemcpyAsync(ref_desc1, x + (size_t)R0 * D, (size_t)R1 * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-    return GFC_ERR_LAUNCH;
-
-  // ---- assignment (lightglue.py:279-288) + filter (lightglue.py:294-319) ----
-  return gfc_lg_assign(p, p->n_layers - 1, x, x + (size_t)R0 * D, B, M, N, threshold, m0, m1, ms0, ms1, log_assignment,
-                       base + pl.qkv, gfc_lg_assign_workspace_bytes(B, M, N), st);
+  // (desc == x is fine here: layer 0 then simply works in place)
+  GFC_TRY(lg_forward_core(p, msg, so, desc == x ? nullptr : desc, size0, size1, B, M, N, threshold, m0, m1, ms0, ms1,
+                          log_assignment, x, base, pl, nullptr, st));
+  if (ref_desc0 && !d2d(ref_desc0, x, (size_t)R0 * 256 * 4)) return GFC_ERR_LAUNCH;
+  if (ref_desc1 && !d2d(ref_desc1, x + (size_t)R0 * 256, (size_t)R1 * 256 * 4)) return GFC_ERR_LAUNCH;
+  return GFC_OK;
 }

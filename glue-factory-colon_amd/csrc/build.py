@@ -4,7 +4,14 @@
 
 hipcc cross-compiles without a GPU; the .so is written next to the Python package
 (in-tree, git-ignored) so that it travels to the GPU box with the repository snapshot.
+
+What is rebuilt is decided by CONTENT, not by file times: every object file carries the sha256 of
+(compiler flags, its source, every header) in `build/<unit>.o.sha256`, and the library carries the
+hash of the whole source set -- both in `build/lib.sha256` and inside the binary: `gfc_version()`
+ends in `src <hash>`, so a process can tell that the library it loaded was built from the sources
+beside it (`source_hash()` here; __graft_entry__.build() checks exactly that).
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -16,6 +23,7 @@ SOURCES = ["runtime.hip", "conv.hip", "conv_split.hip", "conv_wino.hip", "gemm.h
 HEADERS = ["common.h", "runtime.h", os.path.join(PKG, "..", "include", "gfc_amd.h")]
 LIB = os.path.join(PKG, "libgfc_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+VERSION_UNIT = "api.hip"  # compiled with -DGFC_SOURCE_HASH="<hash>": gfc_version() reports it
 
 
 def _hipcc():
@@ -25,45 +33,81 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+def _read(path):
+    with open(path, "rb") as f:
+        return f.read()
+
+
+def _headers():
+    return [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
+
+
+def source_hash():
+    """sha256 (first 12 hex digits) over the compiler flags, every source and every header, in a fixed order."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in [os.path.join(HERE, s) for s in SOURCES] + _headers():
+        h.update(os.path.basename(path).encode() + b"\0" + _read(path) + b"\0")
+    return h.hexdigest()[:12]
+
+
+def _unit_hash(src, extra_flags):
+    h = hashlib.sha256(" ".join(FLAGS + extra_flags).encode())
+    for path in [src] + _headers():
+        h.update(os.path.basename(path).encode() + b"\0" + _read(path) + b"\0")
+    return h.hexdigest()
+
+
+def _stamp_matches(stamp, value):
+    try:
+        return _read(stamp).decode().strip() == value
+    except OSError:
+        return False
 
 
 def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    hdrs = [h if os.path.isabs(h) else os.path.join(HERE, h) for h in HEADERS]
+    whole = source_hash()
     jobs = []
     for s in SOURCES:
         src = os.path.join(HERE, s)
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
-        if force or _stale(obj, [src, *hdrs]):
-            jobs.append((src, obj))
+        extra = [f'-DGFC_SOURCE_HASH="{whole}"'] if s == VERSION_UNIT else []
+        want = _unit_hash(src, extra)
+        if force or not os.path.exists(obj) or not _stamp_matches(obj + ".sha256", want):
+            jobs.append((src, obj, extra, want))
 
     def compile_one(job):
-        src, obj = job
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        src, obj, extra, _ = job
+        cmd = [hipcc, *FLAGS, *extra, "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
-            for (src, obj), r in ex.map(compile_one, jobs):
+            for (src, obj, _, want), r in ex.map(compile_one, jobs):
                 if verbose and (r.stderr.strip() or r.returncode):
                     print(r.stderr, file=sys.stderr)
                 if r.returncode:
                     raise RuntimeError(f"hipcc failed on {src}")
+                with open(obj + ".sha256", "w") as f:
+                    f.write(want)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
+    lib_stamp = os.path.join(objdir, "lib.sha256")
+    relink = force or bool(jobs) or not os.path.exists(LIB) or not _stamp_matches(lib_stamp, whole)
+    if relink:
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode:
             print(r.stderr, file=sys.stderr)
             raise RuntimeError("link failed")
+        with open(lib_stamp, "w") as f:
+            f.write(whole)
+    if verbose:
+        print(f"gfc build: source hash {whole}; compiled {len(jobs)} of {len(SOURCES)} translation units "
+              f"({'forced' if force else 'content hash changed or object missing'}), "
+              f"{'linked' if relink else 'library up to date'}", file=sys.stderr)
     return LIB
 
 

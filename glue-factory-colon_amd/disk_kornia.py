@@ -11,10 +11,12 @@ everything BEHIND the network, as HIP kernels (csrc/disk_detect.hip), restated f
     (n+1)-th score -> descriptors at the integer pixel, L2-normalised -> specular filter (offset 0.5) ->
     pad_and_stack -> +0.5                                                    (disk_kornia.py:42-47,84-137)
 
-The network is supplied as `dense_fn(images [b,3,H,W]) -> (heat-maps [b,1,H,W], descriptors [b,D,H,W])` on the
-device: `kornia.feature.DISK(...).heatmap_and_dense_descriptors` when kornia is importable (third-party arithmetic,
-PyTorch-ROCm), or any callable passed as `DISK(conf, dense_fn=...)`.  Without either, `forward` raises: there is no
-substitute network.  NETWORK PARITY UNPINNED; the post-network stages are tested against oracle/disk.py.
+The network is supplied EXPLICITLY as `dense_fn(images [b,3,H,W]) -> (heat-maps [b,1,H,W], descriptors [b,D,H,W])`
+on the device, passed as `DISK(conf, dense_fn=...)` or `set_dense_fn` (e.g. kornia's
+`DISK.from_pretrained("depth").heatmap_and_dense_descriptors` where that package and its weights exist).  Nothing is
+picked up implicitly: an importable kornia is NOT used by itself (no silent third-party eager network on the product
+path), and without a dense_fn `forward` raises -- there is no substitute network.  NETWORK PARITY UNPINNED; the
+post-network stages are tested against oracle/disk.py.
 
     model.extractor.name = glue_factory_colon_amd.disk_kornia
 """
@@ -49,14 +51,11 @@ class DISK(BaseModel):
     def _init(self, conf):
         self._ws = nat.Workspace()
         if self._dense_fn is None:
-            try:  # the reference's own provider, when present (third-party arithmetic; nothing is downloaded here)
-                import kornia  # noqa: F401
-            except ImportError:
-                return  # not initialised: forward raises until a dense_fn is supplied
-            model = kornia.feature.DISK(desc_dim=conf_get(conf, "desc_dim"))
-            self.model = model
-            object.__setattr__(self, "_dense_fn", model.heatmap_and_dense_descriptors)
-            return  # weights: load_state_dict of a local checkpoint marks it initialised
+            # No network is built into this package (kornia's U-Net source and weights are absent offline, a25 in
+            # DESIGN.md), and kornia's PyTorch network is deliberately NOT picked up even when it is importable: the
+            # product path never runs a third-party eager network silently.  A caller who wants that passes it
+            # explicitly: DISK(conf, dense_fn=kornia.feature.DISK.from_pretrained("depth").heatmap_and_dense_descriptors).
+            return  # not initialised: forward raises until a dense_fn is supplied
         self.set_initialized()
 
     def is_initialized(self):
@@ -133,15 +132,22 @@ class DISK(BaseModel):
                     raise RuntimeError(f"images of one batch yield different numbers of keypoints {n}: "
                                        "use force_num_keypoints=True or batch size 1")
                 n_out = n[0]
-            desc = torch.empty((b, cap, d), device=dev, dtype=torch.float32)
-            for j, i in enumerate(range(0, b, chunk)):  # slots >= count: zeros (pad_and_stack "zeros")
-                dn = dense_all[j]
-                nat.check(lib.gfc_disk_gather_descriptors(nat.ptr(dn), dn.shape[0], d, h, w, nat.ptr(kpts[i:i + dn.shape[0]]),
-                                                          nat.ptr(counts[i:i + dn.shape[0]]), cap,
-                                                          nat.ptr(desc[i:i + dn.shape[0]]), st), "gfc_disk_gather_descriptors")
+            # descriptors only for the slots that are returned: with max_num_keypoints = None the selection arrays have
+            # one slot per pixel (cap = h*w), but n_out is a few thousand -- compact the key points first, then gather
+            # into a [b, n_out, d] array (row capacity of both = n_out)
+            if n_out < cap:
+                kpts, ksc = kpts[:, :n_out].contiguous(), ksc[:, :n_out].contiguous()
+            desc = torch.empty((b, n_out, d), device=dev, dtype=torch.float32)
+            if n_out > 0:
+                for j, i in enumerate(range(0, b, chunk)):  # slots >= count: zeros (pad_and_stack "zeros")
+                    dn = dense_all[j]
+                    nat.check(lib.gfc_disk_gather_descriptors(nat.ptr(dn), dn.shape[0], d, h, w,
+                                                              nat.ptr(kpts[i:i + dn.shape[0]]),
+                                                              nat.ptr(counts[i:i + dn.shape[0]]), n_out,
+                                                              nat.ptr(desc[i:i + dn.shape[0]]), st),
+                              "gfc_disk_gather_descriptors")
             if force:
                 kpts, ksc = pad_keypoints_native(kpts, ksc, counts, n_out, 0, data, image)  # disk_kornia.py:109-124
-            kpts, ksc, desc = kpts[:, :n_out], ksc[:, :n_out], desc[:, :n_out]
         pred = {
             "keypoints": kpts.contiguous().to(image) + 0.5,
             "keypoint_scores": ksc.contiguous().to(image),

@@ -67,12 +67,22 @@ def _process(model, data, keys, optional_keys, callback_fn, as_half):
 def _sharded(loader, rank, world):
     """(index, item) of this rank's round-robin share of the loader (sharding.round_robin_shard: pairs of an
     HPatches-style list differ in size, so consecutive pairs go to different ranks).  A loader that can skip work
-    itself may offer `shard(rank, world)` yielding (index, item); otherwise the other ranks' items are drawn and
-    dropped."""
+    itself may offer `shard(rank, world)` yielding (index, item); a sequential batch-1 torch DataLoader (what the
+    reference's evaluation builds, datasets/base_dataset.py:175-186) is re-created over this rank's Subset of its
+    dataset, so that each rank LOADS only its own items; otherwise the other ranks' items are drawn and dropped."""
+    from torch.utils.data import DataLoader, SequentialSampler, Subset
     if world <= 1:
         yield from enumerate(loader)
     elif hasattr(loader, "shard"):
         yield from loader.shard(rank, world)
+    elif (isinstance(loader, DataLoader) and loader.batch_size == 1 and isinstance(loader.sampler, SequentialSampler)
+          and hasattr(loader.dataset, "__len__") and hasattr(loader.dataset, "__getitem__")):
+        from .sharding import round_robin_shard
+        idx = list(round_robin_shard(len(loader.dataset), rank, world))
+        sub = DataLoader(Subset(loader.dataset, idx), batch_size=1, shuffle=False, num_workers=loader.num_workers,
+                         collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
+                         worker_init_fn=loader.worker_init_fn)
+        yield from zip(idx, sub)
     elif hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
         from .sharding import round_robin_shard
         for i in round_robin_shard(len(loader), rank, world):
@@ -124,16 +134,37 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
     model = model.to(device).eval()
     if world > 1:
         inner = Path(str(output_file) + f".part{rank}")
-        local = []
-        _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half, workers,
-                     local)
-        flat = {f"{idx}|{name}/{k}": v for idx, name, rec in local for k, v in rec.items()}
-        with open(inner, "wb") as fh:
-            np.savez(fh, **flat)
-        dist.barrier()
-        if rank == 0:
-            _merge_parts(output_file, world)
-        dist.barrier()
+        # A rank that fails must not leave the others waiting at a barrier for ever: every rank reports a status
+        # flag through ONE all-reduce (the synchronisation point), and all of them raise together if any failed.
+        failure = None
+        try:
+            local = []
+            _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half,
+                         workers, local)
+            flat = {f"{idx}|{name}/{k}": v for idx, name, rec in local for k, v in rec.items()}
+            with open(inner, "wb") as fh:
+                np.savez(fh, **flat)
+        except Exception as e:  # noqa: BLE001 -- re-raised below, after the other ranks have been told
+            failure = e
+        if _any_rank_failed(failure is not None, device):
+            inner.unlink(missing_ok=True)  # no stale part files after a failed run
+            if failure is not None:
+                raise failure
+            raise RuntimeError("export_predictions: another rank failed; nothing was merged")
+        try:
+            if rank == 0:
+                _merge_parts(output_file, world)
+        except Exception as e:  # noqa: BLE001
+            failure = e
+        finally:
+            failed = _any_rank_failed(failure is not None, device)
+            if failed:
+                for r in range(world) if rank == 0 else ():
+                    Path(str(output_file) + f".part{r}").unlink(missing_ok=True)
+        if failure is not None:
+            raise failure
+        if failed:
+            raise RuntimeError("export_predictions: merging the part files failed on rank 0")
         return output_file
     local = []
     _export_loop(enumerate(loader), model, device, keys, optional_keys, callback_fn, as_half, workers, local)
@@ -143,6 +174,16 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
             records[name] = rec
     _write(output_file, records)
     return output_file
+
+
+def _any_rank_failed(failed_here: bool, device) -> bool:
+    """One all-reduce (MAX) of a per-rank failure flag; doubles as the barrier between the export and merge phases."""
+    import torch.distributed as dist
+    backend = dist.get_backend()
+    flag = torch.tensor([1 if failed_here else 0], dtype=torch.int32,
+                        device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    return bool(flag.item())
 
 
 def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out):

@@ -70,6 +70,18 @@ class _TokenConfidence(nn.Module):
         self.token = nn.Sequential(nn.Linear(d, 1), nn.Sigmoid())
 
 
+def _pack_sides(a, b):
+    """[B,M,C] and [B,N,C] -> [B*M + B*N, C] rows (side 0 first).  A view when `b` starts where `a` ends in the same
+    allocation (both views extracted by one call), a concatenation otherwise."""
+    c = a.shape[-1]
+    ra, rb = a.numel() // c, b.numel() // c
+    if (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == torch.float32
+            and b.data_ptr() == a.data_ptr() + a.numel() * 4
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()):
+        return a.as_strided((ra + rb, c), (c, 1))
+    return torch.cat([a.reshape(ra, c), b.reshape(rb, c)], 0)
+
+
 class LightGlue(nn.Module):
     default_conf = {
         "name": "lightglue",
@@ -117,6 +129,7 @@ class LightGlue(nn.Module):
         self.register_buffer("confidence_thresholds", _weights.confidence_thresholds(n))
         self._packed = None
         self._ws = nat.Workspace()
+        self.trace = None  # optional nat.KernelTrace (bench.py): per-launch events of the attention kernel
         self.are_weights_initialized = False
 
         w = conf.weights
@@ -276,7 +289,7 @@ class LightGlue(nn.Module):
             so0, so1 = pack(data["scales0"], data["oris0"]), pack(data["scales1"], data["oris1"])
         if (conf.depth_confidence > 0 or conf.width_confidence > 0) and m > 0 and n > 0:
             return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1, so0, so1)
-        if m > 0 and n > 0:  # every element of the outputs is written by gfc_lg_forward: no fills
+        if m > 0 and n > 0:  # every element of the outputs is written by gfc_lg_forward_packed: no fills
             alloc = torch.empty
         else:                # the reference's early return (lightglue.py:298-303): all -1 / zeros
             alloc = torch.zeros
@@ -288,22 +301,29 @@ class LightGlue(nn.Module):
         ms0 = alloc((b, m), device=device)
         ms1 = alloc((b, n), device=device)
         scores = alloc((b, m + 1, n + 1), device=device)
-        ref0 = alloc((b, 1, m, conf.descriptor_dim), device=device)
-        ref1 = alloc((b, 1, n, conf.descriptor_dim), device=device)
+        # one row buffer [b*m + b*n, 256]: the library's layers work in place on it and leave the last layer's
+        # descriptors there; ref_descriptors0/1 are its two halves (no copy out)
+        rows = alloc((b * (m + n), conf.descriptor_dim), device=device)
+        ref0 = rows[: b * m].view(b, 1, m, conf.descriptor_dim)
+        ref1 = rows[b * m:].view(b, 1, n, conf.descriptor_dim)
         if m > 0 and n > 0:
             if self._packed is None or self._packed[2] != device:
                 self._packed = self._pack(device)
             lib = nat.lib()
-            ws = self._ws.get(lib.gfc_lg_workspace_bytes(b, m, n), device)
+            ws = self._ws.get(lib.gfc_lg_packed_workspace_bytes(b, m, n), device)
             s0 = torch.as_tensor(size0, device=device, dtype=torch.float32).expand(b, 2).contiguous()
             s1 = torch.as_tensor(size1, device=device, dtype=torch.float32).expand(b, 2).contiguous()
-            k0 = kpts0.contiguous().float()
-            k1 = kpts1.contiguous().float()
-            nat.check(lib.gfc_lg_forward(
-                ctypes.byref(self._packed[0]), nat.ptr(k0), nat.ptr(k1), nat.ptr(desc0), nat.ptr(desc1), nat.ptr(s0),
-                nat.ptr(s1), nat.ptr(so0), nat.ptr(so1), b, m, n, float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0),
-                nat.ptr(ms1), nat.ptr(scores), nat.ptr(ref0), nat.ptr(ref1), nat.ptr(ws), ws.numel(),
-                nat.stream_ptr(device)), "gfc_lg_forward")
+            # side-0 rows then side-1 rows: zero-copy when both views came out of ONE extractor call (adjacent
+            # slices of one tensor), otherwise one concatenation each (tensor plumbing)
+            kp = _pack_sides(kpts0.contiguous().float(), kpts1.contiguous().float())
+            de = _pack_sides(desc0, desc1)
+            so = _pack_sides(so0, so1) if so0 is not None else None
+            nat.check(lib.gfc_lg_forward_packed(
+                ctypes.byref(self._packed[0]), nat.ptr(kp), nat.ptr(de), nat.ptr(s0), nat.ptr(s1), nat.ptr(so), b, m, n,
+                float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0), nat.ptr(ms1), nat.ptr(scores),
+                nat.ptr(rows), nat.ptr(ws), ws.numel(),
+                ctypes.byref(self.trace.c) if self.trace is not None else None,
+                nat.stream_ptr(device)), "gfc_lg_forward_packed")
         # m == 0 or n == 0: the reference's early return (lightglue.py:298-303) -> all -1 / zeros
         return {
             "matches0": m0,

@@ -166,11 +166,12 @@ typedef struct {
 
 typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;
 
-/* Optional per-launch timing of the dominant kernel (host struct owned by the caller, no global
- * state): gfc_sp_dense brackets the launch of the stem kernel (gfc_sp_stem: conv1a + conv1b + pool,
- * 44 % of the extractor's FLOPs) with hipEventRecord(start[count]) / hipEventRecord(stop[count]) on the
- * call's stream and increments count (while count < capacity).  Events come from
- * gfc_event_create().  Used by bench.py for the live roofline figure; NULL in production. */
+/* Optional per-launch timing of a hot kernel (host struct owned by the caller, no global state): the entry point
+ * that takes a gfc_trace brackets every launch of ITS traced kernel with hipEventRecord(start[count]) /
+ * hipEventRecord(stop[count]) on the call's stream and increments count (while count < capacity):
+ *   gfc_sp_dense           -> the stem kernel (conv1a + conv1b + pool, 44 % of the extractor's FLOPs),
+ *   gfc_lg_forward_packed  -> the attention launches (2 per layer: self, cross), the largest share of the step.
+ * Events come from gfc_event_create().  Used by bench.py for the live roofline figures; NULL in production. */
 typedef struct {
   void** start;
   void** stop;
@@ -371,6 +372,19 @@ int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts
                    const float* scale_ori1, int B, int M, int N,
                    float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
                    float* ref_desc0, float* ref_desc1, void* ws, size_t ws_bytes, void* stream);
+
+/* The same matcher on PACKED rows, without a single device-to-device copy: kpts [B*M + B*N, 2] and desc
+ * [B*M + B*N, Din] hold the rows of side 0 (pair-major) followed by the rows of side 1 -- the layout one extractor
+ * call over both views' images produces; scale_ori [B*M + B*N, 2] or NULL likewise.  `rows` [B*M + B*N, 256] is the
+ * caller's row buffer: layer 0 reads the descriptors where they are (desc is never written), every later layer
+ * works in place on `rows`, which ends up holding the last layer's descriptors = ref_descriptors0 (first B*M rows)
+ * and ref_descriptors1.  attention_trace: optional event pairs around the attention launches (see gfc_trace).
+ * Replaces the same reference lines as gfc_lg_forward (lightglue.py:422-553). */
+size_t gfc_lg_packed_workspace_bytes(int B, int M, int N);
+int gfc_lg_forward_packed(const gfc_lg_params* p, const float* kpts, const float* desc, const float* size0,
+                          const float* size1, const float* scale_ori, int B, int M, int N, float threshold, int64_t* m0,
+                          int64_t* m1, float* ms0, float* ms1, float* log_assignment, float* rows, void* ws,
+                          size_t ws_bytes, gfc_trace* attention_trace, void* stream);
 
 /* Nearest-neighbour matcher ("next" row; the matcher of the reference's superpoint+NN configurations):
  * sim = desc0 . desc1^T, top-2 per row / column, ratio test d1 <= ratio^2 d2 and distance test d1 <= th^2 on

@@ -452,7 +452,7 @@ def test_gemm_tile_variants_via_knob():
     for tile in (1, 2, 3, 4, 5, 6, 7, 8):
         env = dict(os.environ, GFC_GEMM_TILE=str(tile))
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
-                            "-k", "linear_plain or linear_concat or linear_rotary or batched_nt", "-p", "no:cacheprovider"],
+                            "-k", "(linear_plain or linear_concat or linear_rotary or batched_nt) and not via_knob", "-p", "no:cacheprovider"],
                            capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
         assert r.returncode == 0, (tile, r.stdout[-800:], r.stderr[-400:])
 
@@ -467,7 +467,7 @@ def test_gemm_epilogue_variants_via_knob():
     for knobs in ({"GFC_GEMM_EPI": "1"}, {"GFC_GEMM_STAGGER": "2"}):
         env = dict(os.environ, **knobs)
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                            "linear_plain or linear_concat or linear_rotary or batched_nt or natural_dispatch_batch32",
+                            "(linear_plain or linear_concat or linear_rotary or batched_nt or natural_dispatch_batch32) and not via_knob",
                             "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
         assert r.returncode == 0, (knobs, r.stdout[-800:], r.stderr[-400:])
 
@@ -492,7 +492,7 @@ def test_attention_variants_via_knob():
     for cfg in (1, 3):
         env = dict(os.environ, GFC_ATTN_CFG=str(cfg))
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
-                            "-k", "(test_attention and not split and not variants and not natural) or cross_attention",
+                            "-k", "((test_attention and not split and not variants and not natural) or cross_attention) and not via_knob",
                             "-p", "no:cacheprovider"],
                            capture_output=True, text=True, env=env, timeout=600, cwd=ROOT)
         assert r.returncode == 0, (cfg, r.stdout[-800:], r.stderr[-400:])
@@ -629,7 +629,7 @@ def test_ffn_fused_variants_via_knob():
 
     env = dict(os.environ, GFC_FFN_FUSED="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "linear_layernorm_gelu_fused", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
+                        "(linear_layernorm_gelu_fused) and not via_knob", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
 
@@ -1030,7 +1030,7 @@ def test_assignment_tail_variants_via_knob():
 
     env = dict(os.environ, GFC_ASSIGN_MODE="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "assignment_head_two_pass", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
+                        "(assignment_head_two_pass) and not via_knob", "-p", "no:cacheprovider"], capture_output=True, text=True, env=env,
                        timeout=600, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
 
@@ -1045,8 +1045,8 @@ def test_dispatch_order_variants_via_knob():
 
     env = dict(os.environ, GFC_XCD_REMAP="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "test_conv3x3_winograd or test_stem_winograd or many_items or test_linear_plain or "
-                        "natural_dispatch or test_attention or test_nms_large or test_fused_nms_select",
+                        "(test_conv3x3_winograd or test_stem_winograd or many_items or test_linear_plain or "
+                        "natural_dispatch or test_attention or test_nms_large or test_fused_nms_select) and not via_knob",
                         "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
 

@@ -13,7 +13,7 @@ import torch
 from glue_factory_colon_amd import _native as nat
 from glue_factory_colon_amd import base_model, lightglue, lightglue_pretrained, registry, sharding, superpoint
 from glue_factory_colon_amd import superpoint_open, synthetic, weights
-from glue_factory_colon_amd._superpoint_common import fold_bn, pad_random_c
+from glue_factory_colon_amd._superpoint_common import fold_bn
 from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -148,16 +148,6 @@ def test_fold_bn_matches_torch_eval_batchnorm():
     assert (x * a[None, :, None, None] + c[None, :, None, None] - ref).abs().max() < 1e-6
 
 
-def test_pad_random_c_semantics():
-    kp = torch.tensor([[[3.0, 7.0], [10.0, 2.0], [0, 0], [0, 0]], [[0, 0]] * 4])
-    sc = torch.tensor([[0.5, 0.4, 9, 9], [9.0, 9, 9, 9]])
-    out, s = pad_random_c(kp, sc, torch.tensor([2, 0]), 4, 0, 48)
-    assert torch.equal(out[0, :2], kp[0, :2]) and torch.equal(s[0], torch.tensor([0.5, 0.4, 0, 0]))
-    assert (out[0, 2:, 0] >= 3).all() and (out[0, 2:, 0] <= 10).all()  # per-column range of the real points
-    assert (out[0, 2:, 1] >= 2).all() and (out[0, 2:, 1] <= 7).all()
-    assert (out[1] >= 0).all() and (out[1] <= 48).all() and (s[1] == 0).all()  # empty image: bounds fallback
-
-
 def test_shard_partitions():
     for n, w in ((256, 8), (540, 8), (7, 3), (2, 4)):
         blocks = [list(sharding.contiguous_shard(n, r, w)) for r in range(w)]
@@ -246,12 +236,15 @@ def test_bench_multiprocess_plumbing_rehearsal():
 
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
-           "--warmup", "1", "--pairs", "4", "--rehearse-cpu"]
+           "--warmup", "1", "--pairs", "4", "--rehearse-cpu", "--cpu-pairs", "1", "--cpu-iters", "1"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["pairs_gathered"] == 8 and out["matches_per_rank"] == [10, 11]
+    # the N > 1 line carries the CPU baseline too (rank 0 times it after the gather; bounded sample here)
+    base = out["cpu_baseline"]
+    assert base is not None and base["value"] > 0 and base["kind"] == "port" and base["cores"] >= 1
 
 
 def test_bench_spawns_its_own_ranks_without_a_launcher():
@@ -262,7 +255,7 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
 
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--pairs",
-           "4", "--rehearse-cpu"]
+           "4", "--rehearse-cpu", "--no-cpu-baseline"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert r.returncode == 0 and len(lines) == 1 and lines[0].startswith("{"), r.stdout + r.stderr
@@ -361,3 +354,23 @@ def test_hdf5_prediction_file_without_h5py(tmp_path):
     got = loader({"name": [items[1]["name"][0]], "scales": items[1]["scales"]})
     assert torch.allclose(got["keypoints"][0], items[1]["x"][0] * 3)  # un-scaled on export, re-scaled on load
     assert torch.equal(got["keypoint_scores"][0], items[1]["x"][0, :, 0])
+
+
+def test_disk_never_picks_up_a_third_party_network_implicitly(monkeypatch):
+    """Config 5 (DISK): an importable `kornia` must NOT become the network by itself -- the product path never runs a
+    third-party eager PyTorch network silently.  Without an explicit dense_fn the module stays uninitialised and its
+    forward raises (reference wrapper: gluefactory/models/extractors/disk_kornia.py:24-47)."""
+    import types
+
+    from glue_factory_colon_amd import disk_kornia
+
+    used = []
+    fake = types.ModuleType("kornia")
+    fake.feature = types.SimpleNamespace(DISK=lambda *a, **k: used.append("constructed"))
+    monkeypatch.setitem(sys.modules, "kornia", fake)
+    m = disk_kornia.DISK({"max_num_keypoints": 64})
+    assert not used and not m.is_initialized()
+    with pytest.raises((RuntimeError, AssertionError)):
+        m({"image": torch.zeros(1, 3, 32, 32)})
+    m2 = disk_kornia.DISK({"max_num_keypoints": 64}, dense_fn=lambda x: (x[:, :1], x))
+    assert m2.is_initialized() and not used

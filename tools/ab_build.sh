@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build a second copy of the library from another git revision of csrc/ for same-box A/B runs:
-#   tools/ab_build.sh <git-rev> [name]   ->  glue-factory-colon_amd/libgfc_amd_<name>.so   (git-ignored, travels with gpurun)
-#   GFC_AMD_LIB=glue-factory-colon_amd/libgfc_amd_<name>.so python tools/bench_kernels.py ...
+#   tools/ab_build.sh <git-rev> [name]   ->  tools/ab_libs/libgfc_amd_<name>.so   (git-ignored, travels with gpurun)
+#   GFC_AMD_LIB=tools/ab_libs/libgfc_amd_<name>.so python tools/bench_kernels.py ...
 # Timings from different GPU boxes differ by up to 10 %: only two libraries timed in one gpurun call are comparable.
 set -euo pipefail
 #   tools/ab_build.sh WORKTREE <name> "-DSOME_DIAGNOSTIC=1"   builds the working tree with extra compiler flags
@@ -25,6 +25,7 @@ for f in *.hip; do
   objs+=("${f%.hip}.o")
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/glue-factory-colon_amd/libgfc_amd_${name}.so" "${objs[@]}"
-echo "$root/glue-factory-colon_amd/libgfc_amd_${name}.so"
+mkdir -p "$root/tools/ab_libs"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$root/tools/ab_libs/libgfc_amd_${name}.so" "${objs[@]}"
+echo "$root/tools/ab_libs/libgfc_amd_${name}.so"
 rm -rf "$tmp"

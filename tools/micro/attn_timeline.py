@@ -2,7 +2,7 @@
 "-DATT_DIAG"): prologue (Q fragments, first K/V tile), key loop, of which: waiting for
 the staged next tile (global loads + LDS writes) and at the workgroup barrier, epilogue.
 
-    GFC_AMD_LIB=glue-factory-colon_amd/libgfc_amd_astamps.so python tools/micro/attn_timeline.py
+    GFC_AMD_LIB=tools/ab_libs/libgfc_amd_astamps.so python tools/micro/attn_timeline.py
 """
 import ctypes
 import os

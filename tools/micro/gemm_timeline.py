@@ -1,7 +1,7 @@
 """Per-wave cycle stamps of gemm_nt_kernel (diagnostic build -DGEMM_DIAG=16, tools/ab_build.sh WORKTREE stamps "-DGEMM_DIAG=16"):
 where do the cycles of a K = 256 GEMM go -- prologue, K loop, epilogue, store drain -- and how busy is each SIMD?
 
-    GFC_AMD_LIB=glue-factory-colon_amd/libgfc_amd_stamps.so python tools/micro/gemm_timeline.py [N] [K] [M]
+    GFC_AMD_LIB=tools/ab_libs/libgfc_amd_stamps.so python tools/micro/gemm_timeline.py [N] [K] [M]
 """
 import ctypes
 import os

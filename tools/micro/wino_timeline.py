@@ -2,7 +2,7 @@
 wstamps "-DWINO_DIAG=256"): cycles between item start and the end of the K loop, in the column transform + exchange
 write + barrier, and in the row transform + stores, summed over a persistent workgroup's items.
 
-    GFC_AMD_LIB=glue-factory-colon_amd/libgfc_amd_wstamps.so python tools/micro/wino_timeline.py
+    GFC_AMD_LIB=tools/ab_libs/libgfc_amd_wstamps.so python tools/micro/wino_timeline.py
 """
 import ctypes
 import os
