@@ -61,26 +61,38 @@ template <int MODE, int NS, int RPS, int ELD>
 __device__ __forceinline__ void gemm_epilogue_round_fast(const GemmArgs& g, const float* patch, float* Y, int row0, int er,
                                                          int ec, int colb, int rd, float4 bi4, float4 sc4, float4 sh4) {
   float4 opa = make_float4(0.f, 0.f, 0.f, 0.f), opb = opa;
+  // ONE running pointer per stream, bumped by a constant stride per step: with per-step 64-bit address arithmetic
+  // (row0 + RPS * i) * ld the unrolled loop kept an address pair per step alive and the 128-register kernel
+  // (gemm_nt_kernel<2,2,16,2>, four workgroups per CU) spilled two of them to scratch
+  const float* pa = nullptr;
+  const float* pb = nullptr;
+  size_t pstep = (size_t)RPS * 64;
   if constexpr (MODE == 1) {
-    opa = *reinterpret_cast<const float4*>(g.rot_cos + (size_t)row0 * 64 + rd);
-    opb = *reinterpret_cast<const float4*>(g.rot_sin + (size_t)row0 * 64 + rd);
+    pa = g.rot_cos + (size_t)row0 * 64 + rd;
+    pb = g.rot_sin + (size_t)row0 * 64 + rd;
+    opa = *reinterpret_cast<const float4*>(pa);
+    opb = *reinterpret_cast<const float4*>(pb);
   } else if constexpr (MODE == 2) {
-    opa = *reinterpret_cast<const float4*>(g.residual + (size_t)row0 * g.ldy + colb);
+    pa = g.residual + (size_t)row0 * g.ldy + colb;
+    pstep = (size_t)RPS * g.ldy;
+    opa = *reinterpret_cast<const float4*>(pa);
   } else if constexpr (MODE == 3) {
-    opa = *reinterpret_cast<const float4*>(g.rot_cs + (size_t)row0 * 64 + rd);
+    pa = g.rot_cs + (size_t)row0 * 64 + rd;
+    opa = *reinterpret_cast<const float4*>(pa);
   }
+  float* yp = Y + (size_t)row0 * g.ldy + colb;
+  const size_t ystep = (size_t)RPS * g.ldy;
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
     float4 na = opa, nb = opb;
     if (i + 1 < NS) {
-      const size_t rn = (size_t)(row0 + RPS * (i + 1));
+      if constexpr (MODE != 0) {
+        pa += pstep;
+        na = *reinterpret_cast<const float4*>(pa);
+      }
       if constexpr (MODE == 1) {
-        na = *reinterpret_cast<const float4*>(g.rot_cos + rn * 64 + rd);
-        nb = *reinterpret_cast<const float4*>(g.rot_sin + rn * 64 + rd);
-      } else if constexpr (MODE == 2) {
-        na = *reinterpret_cast<const float4*>(g.residual + rn * g.ldy + colb);
-      } else if constexpr (MODE == 3) {
-        na = *reinterpret_cast<const float4*>(g.rot_cs + rn * 64 + rd);
+        pb += pstep;
+        nb = *reinterpret_cast<const float4*>(pb);
       }
     }
     float4 v = *reinterpret_cast<const float4*>(patch + (er + RPS * i) * ELD + ec);
@@ -103,7 +115,8 @@ __device__ __forceinline__ void gemm_epilogue_round_fast(const GemmArgs& g, cons
     v.x = v.x * sc4.x + sh4.x; v.y = v.y * sc4.y + sh4.y; v.z = v.z * sc4.z + sh4.z; v.w = v.w * sc4.w + sh4.w;
     v.x *= g.alpha; v.y *= g.alpha; v.z *= g.alpha; v.w *= g.alpha;
     if constexpr (MODE == 2) { v.x = opa.x + v.x; v.y = opa.y + v.y; v.z = opa.z + v.z; v.w = opa.w + v.w; }
-    *reinterpret_cast<float4*>(Y + (size_t)(row0 + RPS * i) * g.ldy + colb) = v;
+    *reinterpret_cast<float4*>(yp) = v;
+    yp += ystep;
     opa = na; opb = nb;
   }
 }

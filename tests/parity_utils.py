@@ -19,10 +19,18 @@ STATS = {}
 def record(name, **kw):
     STATS[name] = {k: (float(v) if not isinstance(v, (int, str)) else v) for k, v in kw.items()}
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-    try:
+    try:  # merged into what is already there: the *_via_knob tests run child pytest processes that record too
         os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "parity_stats.json"), "w") as f:
-            json.dump(STATS, f, indent=1, sort_keys=True)
+        path = os.path.join(out, "parity_stats.json")
+        merged = {}
+        try:
+            with open(path) as f:
+                merged = json.load(f)
+        except (OSError, ValueError):
+            pass
+        merged.update(STATS)
+        with open(path, "w") as f:
+            json.dump(merged, f, indent=1, sort_keys=True)
     except OSError:
         pass
 
