@@ -27,7 +27,7 @@ class SpParams(Structure):
                 ("wp", c_void_p), ("bias_p", c_void_p), ("scale_p", c_void_p), ("shift_p", c_void_p),
                 ("wd", c_void_p), ("bias_d", c_void_p), ("scale_d", c_void_p), ("shift_d", c_void_p),
                 ("desc_dim", c_int), ("conv_mode", c_int), ("w_split", c_void_p * 8), ("wh_split", c_void_p),
-                ("w_wino", c_void_p * 8), ("wh_wino", c_void_p)]
+                ("w_wino", c_void_p * 8), ("wh_wino", c_void_p), ("w_stem_wino43", c_void_p)]
 
 
 class Trace(Structure):
@@ -109,6 +109,8 @@ SIGNATURES = {
     "gfc_pack_conv3x3_wino": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gfc_conv3x3_wino": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "gfc_sp_stem_wino": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "gfc_pack_conv3x3_wino43": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gfc_sp_stem_wino43": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_disk_select_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_disk_nms_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p,

@@ -82,6 +82,13 @@ class PackedSuperPoint:
                 self.params.w_split[i] = pack_split(w).data_ptr()
             if mode == "winograd" and i >= 1:
                 self.params.w_wino[i] = pack_wino(w).data_ptr()
+            if mode == "winograd" and i == 1 and tuple(w.shape[:2]) == (64, 64):
+                # the stem's conv1b additionally as F(4x4,3x3) (csrc/conv_wino43.hip; $GFC_STEM_F43=0 selects F(2x2,3x3))
+                w32 = w.detach().to(device=device, dtype=torch.float32).contiguous()
+                w43 = torch.empty((36 * 64 * 64,), device=device, dtype=torch.float32)
+                nat.check(lib.gfc_pack_conv3x3_wino43(nat.ptr(w32), nat.ptr(w43), 64, 64, st), "gfc_pack_conv3x3_wino43")
+                self.keep.extend([w32, w43])
+                self.params.w_stem_wino43 = w43.data_ptr()
             self.params.bias[i] = dev(b).data_ptr()
             sc, sh = opt(sc), opt(sh)
             self.params.scale[i] = sc.data_ptr() if sc is not None else None
@@ -237,6 +244,24 @@ class SuperPointRunner:
         return x
 
 
+def joint_pair_data(data0, data1):
+    """Two single-view extractor inputs as ONE batch (view 0's images first), or None when they cannot share a call:
+    different image shape / dtype / device, or side inputs (image_size, specular_mask) present in only one of them."""
+    im0, im1 = data0["image"], data1["image"]
+    if im0.shape[1:] != im1.shape[1:] or im0.dtype != im1.dtype or im0.device != im1.device:
+        return None
+    joint = {"image": torch.cat([im0, im1], 0)}
+    for key in ("image_size", "specular_mask"):
+        if (key in data0) != (key in data1):
+            return None
+        if key in data0:
+            a, b = data0[key], data1[key]
+            if a.shape[1:] != b.shape[1:]:
+                return None
+            joint[key] = torch.cat([a.to(im0.device), b.to(im0.device)], 0)
+    return joint
+
+
 def specular_mask_bytes(data, b, device):
     """`data["specular_mask"]` ([B,1,H,W] / [B,H,W], any dtype, non-zero = keep; extractors/utils.py:16-20) as
     contiguous bytes [B,Hm,Wm] on the device, and image_size as int32 [B,2] (w, h) or None."""
@@ -252,10 +277,13 @@ def specular_mask_bytes(data, b, device):
 
 def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection_threshold, max_num_keypoints,
                   force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs, specular=None,
-                  refinement_radius=0):
+                  refinement_radius=0, per_image=False):
     """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379).
     specular: None, "before_topk" (superpoint_open.py:177-188) or "after_topk" (superpoint.py:310-328) when
-    `data["specular_mask"]` is to be applied."""
+    `data["specular_mask"]` is to be applied.
+    per_image: return a list of one prediction dict per image (batch dimension 1 each) instead of one batched dict;
+    images may then yield different numbers of key points (two views of a pair extracted by ONE call,
+    two_view_pipeline.py: the reference runs the extractor once per view, so its views never had to agree)."""
     image = data["image"]
     nat.require_cuda(image, "data['image']")
     if image.dtype != torch.float32:
@@ -293,17 +321,34 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
         counts_arg = None
     else:
         n = counts.tolist()  # host sync, as torch.where in the reference
-        if len(set(n)) != 1:
+        if len(set(n)) != 1 and not per_image:
             # the reference cannot stack ragged key-point lists either (torch.stack raises)
             raise RuntimeError(f"images of one batch yield different numbers of keypoints {n}: "
                                "use force_num_keypoints=True or batch size 1")
-        kpts, ksc = kpts[:, : n[0]].contiguous(), ksc[:, : n[0]].contiguous()
-        counts_arg = None
+        if len(set(n)) == 1:
+            if n[0] != kpts.shape[1]:
+                kpts, ksc = kpts[:, : n[0]].contiguous(), ksc[:, : n[0]].contiguous()
+            counts_arg = None
+        else:
+            counts_arg = counts  # ragged (per_image): the sampler zero-fills the slots beyond each image's count
     if kpts.shape[1] > 0:
         desc, kout = runner.sample(desc_raw, kpts, counts_arg, sample_mode)
     else:
         desc = kpts.new_zeros((b, 0, packed.desc_dim))
         kout = kpts
+    if per_image:
+        lens = n if (not force_num_keypoints and len(set(n)) != 1) else [kout.shape[1]] * b
+        preds = []
+        for i in range(b):
+            # full-length rows stay views of the batched tensors (adjacent in memory: the matcher reads both views'
+            # rows without a copy); shorter rows are trimmed
+            p_i = {"keypoints": kout[i:i + 1, : lens[i]], "keypoint_scores": ksc[i:i + 1, : lens[i]],
+                   "descriptors": desc[i:i + 1, : lens[i]],
+                   "extractor_core_time_ms": image.new_full((1,), core_time_ms / b)}
+            if dense_outputs:
+                p_i["dense_descriptors"] = runner.l2norm_rows(desc_raw[i:i + 1].clone()).permute(0, 3, 1, 2)
+            preds.append(p_i)
+        return preds
     pred = {
         "keypoints": kout,
         "keypoint_scores": ksc,

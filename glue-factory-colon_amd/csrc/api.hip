@@ -142,6 +142,9 @@ static int traced_stem(gfc_trace* tr, hipStream_t st, const gfc_sp_params* p, co
   int s = p->conv_mode == 1
               ? gfc_sp_stem_split(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_split[1], p->bias[1],
                                   p->scale[1], p->shift[1], y, B, H, W, st)
+          : (p->conv_mode == 2 && p->w_stem_wino43 && gfc_knobs().stem_f43 != 0)
+              ? gfc_sp_stem_wino43(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_stem_wino43, p->bias[1],
+                                   p->scale[1], p->shift[1], y, B, H, W, st)
           : p->conv_mode == 2
               ? gfc_sp_stem_wino(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_wino[1], p->bias[1],
                                  p->scale[1], p->shift[1], y, B, H, W, st)

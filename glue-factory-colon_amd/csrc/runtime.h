@@ -22,6 +22,7 @@ struct GfcKnobs {
   int assign_mode;   // GFC_ASSIGN_MODE: 0 = automatic, 1 = five-pass tail, 2 = two-pass tail
   int gemm_epi;      // GFC_GEMM_EPI: 0 = automatic, 1 = float4 stores through the LDS transpose for every epilogue, 2 = direct
   int gemm_stagger;  // GFC_GEMM_STAGGER: start skew of the first-round GEMM workgroups in units of 8128 cycles per wave slot
+  int stem_f43;      // GFC_STEM_F43: 1 (default) = Winograd F(4x4,3x3) stem when its filters are supplied, 0 = F(2x2,3x3) stem
   int xcd_remap;     // GFC_XCD_REMAP: 1 (default) = XCD-aware work order (common.h: gfc_xcd_chunk), 0 = dispatch order
 };
 const GfcKnobs& gfc_knobs();

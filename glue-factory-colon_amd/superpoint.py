@@ -14,7 +14,7 @@ from torch import nn
 
 from . import _native as nat
 from . import weights as _weights
-from ._superpoint_common import SAMPLE_FIXED, SAMPLE_LEGACY, PackedSuperPoint, SuperPointRunner, run_extractor
+from ._superpoint_common import joint_pair_data, SAMPLE_FIXED, SAMPLE_LEGACY, PackedSuperPoint, SuperPointRunner, run_extractor
 from .base_model import BaseModel, conf_get
 
 _LAYERS = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"]
@@ -88,7 +88,7 @@ class SuperPoint(BaseModel):
                                 cv(self.convPb), cv(self.convDb), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic", None))
 
-    def _forward(self, data):
+    def _forward(self, data, per_image=False):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         conf = self.conf
@@ -117,7 +117,20 @@ class SuperPoint(BaseModel):
                 force_num_keypoints=conf_get(conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_LEGACY if conf_get(conf, "legacy_sampling") else SAMPLE_FIXED,
                 use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"), specular=specular,
-                refinement_radius=conf_get(conf, "refinement_radius", 0) or 0)
+                refinement_radius=conf_get(conf, "refinement_radius", 0) or 0, per_image=per_image)
+
+    def forward_pair(self, data0, data1):
+        """Both views of an image pair through ONE extractor call when their images agree in shape (see
+        superpoint_open.SuperPoint.forward_pair).  Returns (pred0, pred1), each exactly what `self(view)` returns."""
+        joint = joint_pair_data(data0, data1) if conf_get(self.conf, "sparse_outputs") else None
+        if joint is None:
+            return self(data0), self(data1)
+        b = data0["image"].shape[0]
+        if b == 1:  # the two views may yield different numbers of key points
+            preds = self._forward(joint, per_image=True)
+            return preds[0], preds[1]
+        pred = self._forward(joint)  # batched views: one count for all images, as in a single-view call
+        return {k: v[:b] for k, v in pred.items()}, {k: v[b:] for k, v in pred.items()}
 
     def loss(self, pred, data):
         raise NotImplementedError

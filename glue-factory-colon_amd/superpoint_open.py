@@ -18,7 +18,7 @@ from torch import nn
 
 from . import _native as nat
 from . import weights as _weights
-from ._superpoint_common import SAMPLE_OPEN, PackedSuperPoint, SuperPointRunner, fold_bn, run_extractor
+from ._superpoint_common import joint_pair_data, SAMPLE_OPEN, PackedSuperPoint, SuperPointRunner, fold_bn, run_extractor
 from .base_model import BaseModel, conf_get
 
 
@@ -101,7 +101,7 @@ class SuperPoint(BaseModel):
                                 blk(self.descriptor[1]), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic"))
 
-    def _forward(self, data):
+    def _forward(self, data, per_image=False):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         specular = "before_topk" if ("specular_mask" in data and conf_get(self.conf, "filter_specular_keypoints")) else None
@@ -118,7 +118,22 @@ class SuperPoint(BaseModel):
                 max_num_keypoints=conf_get(self.conf, "max_num_keypoints"),
                 force_num_keypoints=conf_get(self.conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_OPEN, use_image_size_for_borders=False,
-                dense_outputs=conf_get(self.conf, "dense_outputs"), specular=specular)
+                dense_outputs=conf_get(self.conf, "dense_outputs"), specular=specular, per_image=per_image)
+
+    def forward_pair(self, data0, data1):
+        """Both views of an image pair through ONE extractor call when their images agree in shape (MI355X addition
+        used by TwoViewPipeline: at batch 1 the layers after the stem fill a fraction of the chip, two images
+        fill twice as much; the two descriptor arrays also come out adjacent in memory, which the matcher reads
+        without a copy).  Returns (pred0, pred1), each exactly what `self(view)` returns."""
+        joint = joint_pair_data(data0, data1)
+        if joint is None:
+            return self(data0), self(data1)
+        b = data0["image"].shape[0]
+        if b == 1:  # the two views may yield different numbers of key points
+            preds = self._forward(joint, per_image=True)
+            return preds[0], preds[1]
+        pred = self._forward(joint)  # batched views: one count for all images, as in a single-view call
+        return {k: v[:b] for k, v in pred.items()}, {k: v[b:] for k, v in pred.items()}
 
     def loss(self, pred, data):
         raise NotImplementedError

@@ -28,6 +28,9 @@ class TwoViewPipeline(BaseModel):
         # random key-point rotation of one view (two_view_pipeline.py:38-43,161-276): a training augmentation
         # ("train_only"), never active on the inference path; asking for it at inference time is rejected
         "keypoint_rotation": {"enabled": False, "max_deg": 180.0, "view": 0, "train_only": True},
+        # MI355X addition: extract both views with ONE extractor call when their images agree in shape and the
+        # extractor offers `forward_pair` (same results; `extractor_time_ms` is then the time of that one call)
+        "joint_extraction": True,
     }
     required_data_keys = ["view0", "view1"]
     strict_conf = False
@@ -84,6 +87,20 @@ class TwoViewPipeline(BaseModel):
             pred_i = {**pred_i, **out}
         return pred_i, t_ms, core_ms, mem
 
+    def extract_pair(self, data):
+        """Both views through one extractor call (extractors with `forward_pair`; no cached features involved).
+        None when that does not apply: the caller then extracts the views one after the other like the reference
+        (two_view_pipeline.py:283-284)."""
+        ext = getattr(self, "extractor", None)
+        d0, d1 = data["view0"], data["view1"]
+        if ext is None or not hasattr(ext, "forward_pair") or d0.get("cache") or d1.get("cache"):
+            return None
+        if d0["image"].shape[1:] != d1["image"].shape[1:]:
+            return None
+        (out0, out1), t_ms, mem = self._timed(d0["image"].device, lambda: ext.forward_pair(d0, d1))
+        c0, c1 = out0.pop("extractor_core_time_ms", None), out1.pop("extractor_core_time_ms", None)
+        return out0, out1, t_ms, c0, c1, mem
+
     def _forward(self, data):
         image0, image1 = data["view0"]["image"], data["view1"]["image"]
         device, b = image0.device, image0.shape[0]
@@ -91,8 +108,13 @@ class TwoViewPipeline(BaseModel):
         def full(v):
             return torch.full((b,), float(v), device=device, dtype=torch.float32)
 
-        pred0, t0, c0, mem0 = self.extract_view(data, "0")
-        pred1, t1, c1, mem1 = self.extract_view(data, "1")
+        joint = self.extract_pair(data) if conf_get(self.conf, "joint_extraction", True) else None
+        if joint is not None:
+            pred0, pred1, t0, c0, c1, mem0 = joint
+            t1 = mem1 = None
+        else:
+            pred0, t0, c0, mem0 = self.extract_view(data, "0")
+            pred1, t1, c1, mem1 = self.extract_view(data, "1")
         pred = {**{k + "0": v for k, v in pred0.items()}, **{k + "1": v for k, v in pred1.items()}}
         t_match = mem_match = None
         if hasattr(self, "matcher"):

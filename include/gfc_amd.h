@@ -69,6 +69,15 @@ int gfc_sp_stem_wino(const float* image, const float* w1, const float* b1, const
                      const float* w2_wino, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
                      int W, void* stream);
 
+/* The stem with conv1b as Winograd F(4x4,3x3) (36 instead of 64 products per 4x4 output block and input channel)
+ * and conv1a evaluated on the matrix pipe; same function and arguments as gfc_sp_stem_wino except for the filter
+ * packing (gfc_pack_conv3x3_wino43: [64][64][3][3] -> 36*64*64 floats in MFMA-fragment order, transform in float64).
+ * superpoint_open.py:61-77,100-108; superpoint.py:214-218. */
+int gfc_pack_conv3x3_wino43(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
+int gfc_sp_stem_wino43(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
+                       const float* w2_wino43, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
+                       int W, void* stream);
+
 /* Extractor stem: conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in ONE launch.  The first layer is
  * recomputed per workgroup on the 18x18 halo of its 16x16 tile from a 20x20 image patch in LDS, so its
  * [B,H,W,64] output (the largest activation of the network) never exists in HBM.
@@ -162,6 +171,11 @@ typedef struct {
    * is still used.  Every product and accumulation is fp32; 2.25x fewer multiplications than conv_mode 0. */
   const float* w_wino[8];
   const float* wh_wino;
+  /* conv_mode = 2, optional: conv1b's filters transformed for Winograd F(4x4,3x3) and packed by
+   * gfc_pack_conv3x3_wino43.  When set, the stem (conv1a + conv1b + pool) runs as gfc_sp_stem_wino43; NULL (or
+   * $GFC_STEM_F43=0): gfc_sp_stem_wino (F(2x2,3x3), w_wino[1]).  Only the stem: for deeper layers F(4x4,3x3) does
+   * not hold the 1e-5 heat-map bar (tools/micro/winograd_f43_numerics.py). */
+  const float* w_stem_wino43;
 } gfc_sp_params;
 
 typedef enum { GFC_SAMPLE_OPEN = 0, GFC_SAMPLE_LEGACY = 1, GFC_SAMPLE_FIXED = 2 } gfc_sample_mode;

@@ -57,6 +57,12 @@ int main(int argc, char** argv) {
       GFC_OK_(gfc_pack_conv3x3_wino(dw, dq, cout[i], cin[i], st));
       p.w_wino[i] = dq;
     }
+    if (i == 1) {  // the stem's conv1b additionally as Winograd F(4x4,3x3): what the boundary modules run by default
+      float* d43 = nullptr;
+      HIP_OK(hipMalloc(&d43, (size_t)36 * 64 * 64 * 4));
+      GFC_OK_(gfc_pack_conv3x3_wino43(dw, d43, 64, 64, st));
+      p.w_stem_wino43 = d43;
+    }
   }
   {
     std::vector<float> w = rd((size_t)512 * 128 * 9), b = rd(512), sc = rd(512), sh = rd(512);
