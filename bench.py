@@ -44,11 +44,12 @@ H, W, K = 480, 640, 1024
 # (0.35 + 22.65 GFLOP; the halo recomputation of conv1a is not counted)
 STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * 480 * 640
 PAIR_FLOPS = 182.3e9  # whole path per pair at this configuration (direct arithmetic)
-# what the matrix pipe executes per pair on the default path: 3x3 convolutions after conv1a at 4/9
-# (Winograd F(2x2,3x3)), conv1a beside the pipe, 1x1 heads and LightGlue as counted by SURVEY.md 8d with out_proj /
-# to_out folded into ffn[0] (-9 x 4 x 2*1024*256*256 = -4.83 GFLOP) and the second cross direction's sim re-evaluated
-# (+9 x 2*1024*1024*64*4 = +4.83 GFLOP): 2 x (4/9 x 50.96 + 0.79) + 78.11 = 125.0 GFLOP
-PAIR_FLOPS_EXECUTED = 2 * (4.0 / 9.0 * 50.96e9 + 0.79e9) + 78.11e9 - 4.83e9 + 4.83e9
+# what the matrix pipe executes per pair on the default path: the stem (conv1a + conv1b) as 2504 MFMAs per
+# 32x16-pixel item = 6.15 GFLOP / image (F(4x4,3x3)), the other 3x3 convolutions (28.31 GFLOP direct) at 4/9 (Winograd
+# F(2x2,3x3)), 1x1 heads and LightGlue as counted by SURVEY.md 8d with out_proj / to_out folded into ffn[0]
+# (-9 x 4 x 2*1024*256*256 = -4.83 GFLOP) and the second cross direction's sim re-evaluated (+9 x 2*1024*1024*64*4 =
+# +4.83 GFLOP): 2 x (6.15 + 4/9 x 28.31 + 0.79) + 78.11 = 117.2 GFLOP
+PAIR_FLOPS_EXECUTED = 2 * (2504 * 4096 * 600 + 4.0 / 9.0 * 28.31e9 + 0.79e9) + 78.11e9 - 4.83e9 + 4.83e9
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -179,8 +180,15 @@ def conv_mode_of(arg):
     return arg if arg is not None else os.environ.get("GFC_CONV_MODE", "winograd")
 
 
+def stem_is_f43(arg):
+    """The default stem: conv1b as Winograd F(4x4,3x3), conv1a on the matrix pipe (csrc/conv_wino43.hip)."""
+    return conv_mode_of(arg) == "winograd" and os.environ.get("GFC_STEM_F43", "1") != "0"
+
+
 def stem_kernel_name(arg):
     mode = conv_mode_of(arg)
+    if stem_is_f43(arg):
+        return "stem_wino43_kernel (stem: conv1a on the matrix pipe + conv1b Winograd F(4x4,3x3) + ReLU + BN + 2x2 max-pool)"
     if mode == "winograd":
         return "conv3x3_wino_kernel<true, true> (stem: conv1a direct + conv1b Winograd F(2x2,3x3) + ReLU + BN + 2x2 max-pool)"
     if mode == "split":
@@ -512,9 +520,16 @@ def main():
         imgs_per_launch = 2 * b if args.joint_extract else b
         stem_alg = STEM_FLOPS_PER_IMAGE * imgs_per_launch  # direct-convolution FLOPs of SURVEY.md 8d
         # Winograd F(2x2,3x3): 16 instead of 36 multiplications per 2x2 output block and input channel, so the matrix
-        # pipe executes 4/9 of conv1b's direct FLOPs (conv1a, cin = 1, runs beside it)
-        stem_exec = (2 * 4 * 64 * 64 * H * W * imgs_per_launch) if wino else stem_alg
-        stem_traffic, stem_src = pmc_traffic_bytes("conv3x3_wino_kernel<true, true") if default_shape else (None, None)
+        # pipe executes 4/9 of conv1b's direct FLOPs (conv1a, cin = 1, runs beside it on the VALU).
+        # F(4x4,3x3) stem (default): 36 per 4x4 block = 1/4 of conv1b's direct FLOPs, plus conv1a on the pipe: per
+        # 32x16-pixel work item 36 positions x 2 cout tiles x 32 k steps + 40 conv1a units x 5 = 2504 MFMAs of 4096 FLOP
+        if stem_is_f43(args.conv_arithmetic):
+            stem_exec = 2504 * 4096 * ((H + 15) // 16) * ((W + 31) // 32) * imgs_per_launch
+        else:
+            stem_exec = (2 * 4 * 64 * 64 * H * W * imgs_per_launch) if wino else stem_alg
+        stem_traffic, stem_src = (pmc_traffic_bytes("stem_wino43_kernel" if stem_is_f43(args.conv_arithmetic)
+                                                    else "conv3x3_wino_kernel<true, true")
+                                  if default_shape else (None, None))
         kernels.append(
             {"kernel": stem_kernel_name(args.conv_arithmetic), "launches_timed": len(durs),
              "avg_launch_ms": round(stem_ms / max(len(durs), 1), 4),
@@ -531,7 +546,7 @@ def main():
                      f"{imgs_per_launch * (H // 2) * (W // 2) * 64 * 4 / 1e6:.1f} MB out"})
         roof["kernels"] = kernels
 
-        exec_pair_flops = PAIR_FLOPS_EXECUTED if args.workload == "c2" and wino else None
+        exec_pair_flops = PAIR_FLOPS_EXECUTED if args.workload == "c2" and stem_is_f43(args.conv_arithmetic) else None
         out = {
             "metric": METRIC if args.workload == "c2" else "image-pairs/sec (SuperPoint+LightGlue, 2048 kpts, 1024x1024)",
             "value": round(value, 3),

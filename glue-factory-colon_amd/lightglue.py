@@ -12,6 +12,7 @@ sub-modules are parameter containers only; the forward pass is one call into lib
 """
 import ctypes
 import os
+import threading
 from pathlib import Path
 
 import torch
@@ -70,6 +71,9 @@ class _TokenConfidence(nn.Module):
         self.token = nn.Sequential(nn.Linear(d, 1), nn.Sigmoid())
 
 
+_CAPTURE_LOCK = threading.Lock()  # one stream capture at a time per process
+
+
 def _pack_sides(a, b):
     """[B,M,C] and [B,N,C] -> [B*M + B*N, C] rows (side 0 first).  A view when `b` starts where `a` ends in the same
     allocation (both views extracted by one call), a concatenation otherwise."""
@@ -104,6 +108,12 @@ class LightGlue(nn.Module):
         # MI355X-specific: fold out_proj / to_out into the first FFN matrix at load time (one GEMM and one
         # [rows,256] HBM round trip less per block; same function, rounding differs by ~1e-7 relative)
         "fold_out_proj": True,
+        # MI355X-specific, opt-in: problems of at most this many rows (b * (m + n); batch-1 evaluation: 2048) replay the
+        # matcher's ~100 launches as ONE captured HIP graph per (b, m, n) (static buffers, inputs copied in, outputs
+        # copied out).  Same kernels, same results.  0 (default) = eager launches: measured at batch 1 the graph saves
+        # 0.05 of 1.65 ms per pair (the matcher is bound by its small grids, not by launch gaps),
+        # and HIP refuses concurrent captures from several host threads (export_predictions(workers > 1)).
+        "graph_max_rows": 0,
     }
     required_data_keys = ["keypoints0", "keypoints1", "descriptors0", "descriptors1"]
 
@@ -130,6 +140,7 @@ class LightGlue(nn.Module):
         self._packed = None
         self._ws = nat.Workspace()
         self.trace = None  # optional nat.KernelTrace (bench.py): per-launch events of the attention kernel
+        self._graphs = {}  # (b, m, n, device, has scale/ori) -> captured launch sequence + its static buffers
         self.are_weights_initialized = False
 
         w = conf.weights
@@ -157,10 +168,73 @@ class LightGlue(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self._packed = None
+        self._graphs = {}
         return super()._apply(fn, *args, **kwargs)
 
     def is_initialized(self):
         return self.are_weights_initialized
+
+    def __deepcopy__(self, memo):
+        """Replicas (export_predictions workers) get their own parameters and workspaces; captured graphs and packed
+        weight pointers belong to the original and are rebuilt by the copy on first use."""
+        import copy
+
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_graphs":
+                new.__dict__[k] = {}
+            elif k == "_packed":
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
+    # -- small problems: the whole launch sequence as one HIP graph ------------------------
+    def _launch_packed(self, kp, de, s0, s1, so, b, m, n, m0, m1, ms0, ms1, scores, rows, ws, trace=None):
+        lib = nat.lib()
+        nat.check(lib.gfc_lg_forward_packed(
+            ctypes.byref(self._packed[0]), nat.ptr(kp), nat.ptr(de), nat.ptr(s0), nat.ptr(s1), nat.ptr(so), b, m, n,
+            float(self.conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0), nat.ptr(ms1), nat.ptr(scores),
+            nat.ptr(rows), nat.ptr(ws), ws.numel(), ctypes.byref(trace.c) if trace is not None else None,
+            nat.stream_ptr(kp.device)), "gfc_lg_forward_packed")
+
+    def _graph_entry(self, key, kp, de, s0, s1, so, b, m, n):
+        """Static buffers + the captured launch sequence of gfc_lg_forward_packed for one problem shape."""
+        device, d = kp.device, self.conf.descriptor_dim
+        lib = nat.lib()
+        e = {"kp": torch.empty_like(kp), "de": torch.empty_like(de), "s0": torch.empty_like(s0),
+             "s1": torch.empty_like(s1), "so": None if so is None else torch.empty_like(so),
+             "m0": torch.empty((b, m), device=device, dtype=torch.long),
+             "m1": torch.empty((b, n), device=device, dtype=torch.long),
+             "ms0": torch.empty((b, m), device=device), "ms1": torch.empty((b, n), device=device),
+             "scores": torch.empty((b, m + 1, n + 1), device=device),
+             "rows": torch.empty((b * (m + n), d), device=device),
+             "ws": torch.empty(int(lib.gfc_lg_packed_workspace_bytes(b, m, n)), dtype=torch.uint8, device=device)}
+        for name, src in (("kp", kp), ("de", de), ("s0", s0), ("s1", s1), ("so", so)):
+            if src is not None:
+                e[name].copy_(src)
+
+        def run():
+            self._launch_packed(e["kp"], e["de"], e["s0"], e["s1"], e["so"], b, m, n, e["m0"], e["m1"], e["ms0"],
+                                e["ms1"], e["scores"], e["rows"], e["ws"])
+
+        # one eager run first (per-kernel attributes are set on first use), then the capture
+        side = torch.cuda.Stream(device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream(device).wait_stream(side)
+        try:
+            with _CAPTURE_LOCK:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                    run()
+            e["graph"] = graph
+        except Exception:  # noqa: BLE001 -- e.g. another thread is using the device: this shape stays eager
+            e = {"graph": None}
+        self._graphs[key] = e
+        return e
 
     def _pack(self, device):
         conf = self.conf
@@ -289,28 +363,12 @@ class LightGlue(nn.Module):
             so0, so1 = pack(data["scales0"], data["oris0"]), pack(data["scales1"], data["oris1"])
         if (conf.depth_confidence > 0 or conf.width_confidence > 0) and m > 0 and n > 0:
             return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1, so0, so1)
-        if m > 0 and n > 0:  # every element of the outputs is written by gfc_lg_forward_packed: no fills
-            alloc = torch.empty
-        else:                # the reference's early return (lightglue.py:298-303): all -1 / zeros
-            alloc = torch.zeros
-        m0 = alloc((b, m), device=device, dtype=torch.long)
-        m1 = alloc((b, n), device=device, dtype=torch.long)
-        if not (m > 0 and n > 0):
-            m0.fill_(-1)
-            m1.fill_(-1)
-        ms0 = alloc((b, m), device=device)
-        ms1 = alloc((b, n), device=device)
-        scores = alloc((b, m + 1, n + 1), device=device)
-        # one row buffer [b*m + b*n, 256]: the library's layers work in place on it and leave the last layer's
-        # descriptors there; ref_descriptors0/1 are its two halves (no copy out)
-        rows = alloc((b * (m + n), conf.descriptor_dim), device=device)
-        ref0 = rows[: b * m].view(b, 1, m, conf.descriptor_dim)
-        ref1 = rows[b * m:].view(b, 1, n, conf.descriptor_dim)
+        d = conf.descriptor_dim
         if m > 0 and n > 0:
             if self._packed is None or self._packed[2] != device:
                 self._packed = self._pack(device)
+                self._graphs = {}
             lib = nat.lib()
-            ws = self._ws.get(lib.gfc_lg_packed_workspace_bytes(b, m, n), device)
             s0 = torch.as_tensor(size0, device=device, dtype=torch.float32).expand(b, 2).contiguous()
             s1 = torch.as_tensor(size1, device=device, dtype=torch.float32).expand(b, 2).contiguous()
             # side-0 rows then side-1 rows: zero-copy when both views came out of ONE extractor call (adjacent
@@ -318,12 +376,39 @@ class LightGlue(nn.Module):
             kp = _pack_sides(kpts0.contiguous().float(), kpts1.contiguous().float())
             de = _pack_sides(desc0, desc1)
             so = _pack_sides(so0, so1) if so0 is not None else None
-            nat.check(lib.gfc_lg_forward_packed(
-                ctypes.byref(self._packed[0]), nat.ptr(kp), nat.ptr(de), nat.ptr(s0), nat.ptr(s1), nat.ptr(so), b, m, n,
-                float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(ms0), nat.ptr(ms1), nat.ptr(scores),
-                nat.ptr(rows), nat.ptr(ws), ws.numel(),
-                ctypes.byref(self.trace.c) if self.trace is not None else None,
-                nat.stream_ptr(device)), "gfc_lg_forward_packed")
+            use_graph = (0 < b * (m + n) <= int(conf.graph_max_rows or 0) and self.trace is None
+                         and os.environ.get("GFC_LG_GRAPH", "1") != "0")
+            if use_graph:
+                key = (b, m, n, device.index, so is not None, torch.cuda.current_stream(device).cuda_stream)
+                e = self._graphs.get(key) or self._graph_entry(key, kp, de, s0, s1, so, b, m, n)
+                use_graph = e["graph"] is not None
+            if use_graph:
+                for name, src in (("kp", kp), ("de", de), ("s0", s0), ("s1", s1), ("so", so)):
+                    if src is not None:
+                        e[name].copy_(src)
+                e["graph"].replay()
+                # the graph owns its buffers: the caller gets copies (plumbing; 6 MB at 1024 x 1024 points)
+                m0, m1, ms0, ms1 = e["m0"].clone(), e["m1"].clone(), e["ms0"].clone(), e["ms1"].clone()
+                scores, rows = e["scores"].clone(), e["rows"].clone()
+            else:
+                # every element of the outputs is written by gfc_lg_forward_packed: no fills
+                m0 = torch.empty((b, m), device=device, dtype=torch.long)
+                m1 = torch.empty((b, n), device=device, dtype=torch.long)
+                ms0, ms1 = torch.empty((b, m), device=device), torch.empty((b, n), device=device)
+                scores = torch.empty((b, m + 1, n + 1), device=device)
+                # one row buffer [b*m + b*n, 256]: the library's layers work in place on it and leave the last layer's
+                # descriptors there; ref_descriptors0/1 are its two halves (no copy out)
+                rows = torch.empty((b * (m + n), d), device=device)
+                ws = self._ws.get(lib.gfc_lg_packed_workspace_bytes(b, m, n), device)
+                self._launch_packed(kp, de, s0, s1, so, b, m, n, m0, m1, ms0, ms1, scores, rows, ws, self.trace)
+        else:  # the reference's early return (lightglue.py:298-303): all -1 / zeros
+            m0 = torch.full((b, m), -1, device=device, dtype=torch.long)
+            m1 = torch.full((b, n), -1, device=device, dtype=torch.long)
+            ms0, ms1 = torch.zeros((b, m), device=device), torch.zeros((b, n), device=device)
+            scores = torch.zeros((b, m + 1, n + 1), device=device)
+            rows = torch.zeros((b * (m + n), d), device=device)
+        ref0 = rows[: b * m].view(b, 1, m, d)
+        ref1 = rows[b * m:].view(b, 1, n, d)
         # m == 0 or n == 0: the reference's early return (lightglue.py:298-303) -> all -1 / zeros
         return {
             "matches0": m0,

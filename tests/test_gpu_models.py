@@ -461,6 +461,27 @@ def test_lightglue_without_image_size(golden):
     assert (ref["log_assignment"] - g["b2_log_assignment"]).abs().max() > 1e-3
 
 
+def test_lightglue_graph_replay_equals_eager(golden):
+    """`graph_max_rows` > 0 (opt-in): the matcher's launch sequence captured as one HIP graph per problem shape and
+    replayed on new inputs gives every output tensor bit-identical to the eager launches (same kernels)."""
+    g = golden("lightglue")
+    d = lg_data(g)
+    eager = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+    graph = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "graph_max_rows": 8192}).eval().to(DEV)
+    keys = ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment", "ref_descriptors0",
+            "ref_descriptors1")
+    gen_ = torch.Generator().manual_seed(3)
+    for it in range(3):  # 0: capture + replay, 1..2: replays with other inputs of the same shape
+        dd = dict(d)
+        if it:
+            dd["descriptors0"] = torch.nn.functional.normalize(
+                d["descriptors0"] + 0.3 * torch.randn(d["descriptors0"].shape, generator=gen_).to(DEV), dim=-1)
+        pe, pg = eager(dd), graph(dd)
+        for k in keys:
+            assert torch.equal(pe[k], pg[k]), (it, k)
+    assert any(e["graph"] is not None for e in graph._graphs.values())  # the graph path was really taken
+
+
 def test_lightglue_empty_set():
     m = lightglue.LightGlue({"weights": "synthetic"}).eval().to(DEV)
     size = torch.tensor([[64.0, 48.0]], device=DEV)
