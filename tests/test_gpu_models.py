@@ -675,3 +675,87 @@ def test_c4_pair_1024x1024_k2048_vs_oracle():
     theirs = match_pairs(okp[0], okp[1], ref["matches0"][0])
     assert len(theirs) > 1000 and len(mine ^ theirs) <= 2, (len(mine), len(theirs), len(mine ^ theirs))
     record("c4_pair_vs_oracle", ref_matches=len(theirs), identical=len(mine & theirs))
+
+
+# ------------------------------------------------------------------- round 3: entry points and plumbing variants
+def test_lg_forward_separate_arrays_equals_packed(golden):
+    """The C entry point for separately allocated sides, gfc_lg_forward (key points / descriptors of the two images in
+    unrelated buffers, ref_descriptors copied out), against the packed zero-copy entry point the module uses
+    (gfc_lg_forward_packed): every output bit-identical.  lightglue.py:422-553."""
+    import ctypes
+
+    from glue_factory_colon_amd import _native as nat
+
+    g = golden("lightglue")
+    d = lg_data(g)
+    m = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+    pred = m(d)
+    lib = nat.lib()
+    k0, k1 = d["keypoints0"].contiguous().float().clone(), d["keypoints1"].contiguous().float().clone()
+    pad = torch.zeros(12345, device=DEV)  # keeps the two descriptor arrays apart in memory
+    de0, de1 = d["descriptors0"].contiguous().float().clone(), d["descriptors1"].contiguous().float().clone()
+    b, mm, nn_ = k0.shape[0], k0.shape[1], k1.shape[1]
+    assert de1.data_ptr() != de0.data_ptr() + de0.numel() * 4 and pad.numel()
+    size = d["view0"]["image_size"].float().expand(b, 2).contiguous()
+    m0 = torch.empty((b, mm), device=DEV, dtype=torch.long)
+    m1 = torch.empty((b, nn_), device=DEV, dtype=torch.long)
+    ms0, ms1 = torch.empty((b, mm), device=DEV), torch.empty((b, nn_), device=DEV)
+    la = torch.empty((b, mm + 1, nn_ + 1), device=DEV)
+    r0, r1 = torch.empty((b, mm, 256), device=DEV), torch.empty((b, nn_, 256), device=DEV)
+    ws = torch.empty(int(lib.gfc_lg_workspace_bytes(b, mm, nn_)), dtype=torch.uint8, device=DEV)
+    nat.check(lib.gfc_lg_forward(ctypes.byref(m._packed[0]), nat.ptr(k0), nat.ptr(k1), nat.ptr(de0), nat.ptr(de1),
+                                 nat.ptr(size), nat.ptr(size), None, None, b, mm, nn_, 0.1, nat.ptr(m0), nat.ptr(m1),
+                                 nat.ptr(ms0), nat.ptr(ms1), nat.ptr(la), nat.ptr(r0), nat.ptr(r1), nat.ptr(ws),
+                                 ws.numel(), nat.stream_ptr(torch.device(DEV))), "gfc_lg_forward")
+    torch.cuda.synchronize()
+    assert torch.equal(m0, pred["matches0"]) and torch.equal(m1, pred["matches1"])
+    assert torch.equal(ms0, pred["matching_scores0"]) and torch.equal(ms1, pred["matching_scores1"])
+    assert torch.equal(la, pred["log_assignment"])
+    assert torch.equal(r0, pred["ref_descriptors0"][:, 0]) and torch.equal(r1, pred["ref_descriptors1"][:, 0])
+    # the caller's descriptors are read-only for both entry points
+    assert torch.equal(de0, d["descriptors0"].float()) and torch.equal(de1, d["descriptors1"].float())
+
+
+@pytest.mark.parametrize("variant", ["open", "official"])
+@pytest.mark.parametrize("threshold,k", [(0.0, 256), (0.02, 512)])
+def test_two_view_joint_extraction_equals_sequential(variant, threshold, k):
+    """TwoViewPipeline with both views in ONE extractor call (`joint_extraction`, default) against the reference's order
+    (view 0, then view 1; two_view_pipeline.py:283-284): every prediction tensor bit-identical.  The second case has
+    a detection threshold under which the two views keep DIFFERENT numbers of key points (ragged per-image split)."""
+    name = "extractors.superpoint_open" if variant == "open" else "gluefactory_nonfree.superpoint"
+    conf = {"extractor": {"name": name, "weights": "synthetic", "max_num_keypoints": k,
+                          "detection_threshold": threshold, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue", "weights": "synthetic", "filter_threshold": 0.1}}
+    v0, v1 = synthetic.synthetic_pairs(1, 160, 208, seed=11)
+    size = torch.tensor([[208.0, 160.0]], device=DEV)
+    data = {"view0": {"image": v0.to(DEV), "image_size": size}, "view1": {"image": v1.to(DEV), "image_size": size}}
+    pj = TwoViewPipeline({**conf, "joint_extraction": True}).eval().to(DEV)(data)
+    ps = TwoViewPipeline({**conf, "joint_extraction": False}).eval().to(DEV)(data)
+    if threshold > 0:
+        assert pj["keypoints0"].shape[1] != pj["keypoints1"].shape[1]  # the ragged case really is ragged
+        assert 0 < pj["keypoints0"].shape[1] < k
+    for key in ps:
+        if key.endswith("_ms") or key.endswith("_mb"):
+            continue
+        assert pj[key].shape == ps[key].shape, key
+        assert torch.equal(pj[key], ps[key]), key
+
+
+def test_forward_pair_batched_views():
+    """forward_pair with b = 2 images per view (force_num_keypoints): the two halves of one 4-image call equal two
+    2-image calls."""
+    ext = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": 300, "detection_threshold": 0.0,
+                                      "nms_radius": 3, "force_num_keypoints": True}).eval().to(DEV)
+    v0, v1 = synthetic.synthetic_pairs(2, 120, 160, seed=5)
+    size = torch.tensor([[160.0, 120.0]] * 2, device=DEV)
+    d0, d1 = {"image": v0.to(DEV), "image_size": size}, {"image": v1.to(DEV), "image_size": size}
+    torch.manual_seed(3)
+    p0, p1 = ext.forward_pair(d0, d1)
+    torch.manual_seed(3)
+    q0 = ext(d0)
+    q1 = ext(d1)
+    assert (p0["keypoint_scores"] > 0).all() and (p1["keypoint_scores"] > 0).all()  # no random padding involved
+    for key in ("keypoints", "keypoint_scores", "descriptors"):
+        assert torch.equal(p0[key], q0[key]) and torch.equal(p1[key], q1[key]), key
+    # adjacent in memory: what lets the matcher read both sides without a copy
+    assert p1["descriptors"].data_ptr() == p0["descriptors"].data_ptr() + p0["descriptors"].numel() * 4

@@ -1,7 +1,7 @@
 # HIP API calls per bench step: difference of two traced runs with 1 and 3 steps
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for n in 1 3; do
-  rocprofv3 --hip-trace --output-format csv -d gpurun_out/hiptrace$n -- python3 bench.py --steps $n --warmup 0 --no-cpu-baseline --no-experimental --no-self-check > /dev/null 2>&1
+  rocprofv3 --hip-trace --output-format csv -d gpurun_out/hiptrace$n -- python3 bench.py --steps $n --warmup 0 --no-cpu-baseline --no-self-check --no-batch1 > /dev/null 2>&1
 done
 python3 - <<'PY'
 import csv, collections, glob
