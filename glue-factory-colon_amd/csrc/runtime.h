@@ -17,7 +17,6 @@ struct GfcKnobs {
   int attn_split;    // GFC_ATTN_SPLIT: 0 = automatic key split
   int conv_kc;       // GFC_CONV_KC: 0 = automatic
   int conv_persist;  // GFC_CONV_PERSIST: -1 = automatic
-  int cross_mode;    // GFC_CROSS_MODE: 0 = automatic, 1 = two one-directional problems, 2 = shared-sim kernel
   int ffn_fused;     // GFC_FFN_FUSED: -1 = automatic, 0 = GEMM + layernorm_gelu pass, 1 = row-owning fused GEMM
   int assign_mode;   // GFC_ASSIGN_MODE: 0 = automatic, 1 = five-pass tail, 2 = two-pass tail
   int gemm_epi;      // GFC_GEMM_EPI: 0 = automatic, 1 = float4 stores through the LDS transpose for every epilogue, 2 = direct
