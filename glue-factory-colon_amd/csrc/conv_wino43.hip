@@ -49,7 +49,7 @@
 #define S4_EX (6 * 2 * 32 * 32)                // exchange buffer floats (one cout tile, one column pair): [xi][jj][tile][cout]
 #define S4_THREADS 768
 #ifndef S4_DIAG
-#define S4_DIAG 0  // diagnostic builds (tools/ab_build.sh WORKTREE s4 "-DS4_DIAG=1"): 1 = per-wave phase accounting (tools/micro/stem43_timeline.py)
+#define S4_DIAG 0  // diagnostic builds (tools/ab_build.sh WORKTREE s4 "-DS4_DIAG=1"): 1 = per-wave phase accounting (tools/micro/stem43_timeline.py); ablations with wrong results: 2 no conv1a stores, 4 no conv1a units inside the chunks, 8 no patch reads, 16 no filter-fragment loads, 32 no epilogue
 #endif
 #if S4_DIAG & 1
 static unsigned long long* g_s4_diag = nullptr;
@@ -130,7 +130,13 @@ __device__ __forceinline__ v2f v2_mul(float s, v2f a) { return v2f{s * a.x, s * 
 // LDS read of one channel pair.  volatile: hipcc would otherwise fuse neighbouring reads into ds_read2_b64, which is
 // banked modulo 32 in 16-lane groups (2-way conflicts on this layout) at half the bandwidth of ds_read_b64
 typedef const volatile __attribute__((address_space(3))) v2f* lds_v2f_ptr;
-__device__ __forceinline__ v2f lds_pair(const float* p) { return *(lds_v2f_ptr)(p); }
+__device__ __forceinline__ v2f lds_pair(const float* p) {
+#if S4_DIAG & 8
+  return v2f{(float)(size_t)p, 1.f};
+#else
+  return *(lds_v2f_ptr)(p);
+#endif
+}
 
 __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args args) {
   // (plain locals: the lambdas below capture by reference, and a by-value kernel argument struct whose address is
@@ -209,6 +215,10 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
   const int ro0 = rP * S4_PITCH * 8, ro1 = rQ * S4_PITCH * 8, ro2 = rR * S4_PITCH * 8, ro3 = rS * S4_PITCH * 8;
   const bool hiR = rR >= 4, hiS = rS >= 4;  // rho = 4, 5: swizzle B
 
+#if S4_DIAG & 1
+  unsigned long long dg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long dg_t0 = __builtin_readcyclecounter();
+#endif
   // ---- conv1a on the matrix pipe: one unit = 32 patch pixels x 32 channels (two chunks) ----
   //   A[pixel][k]: image taps (k = 9: constant 1 -> bias), B[k][channel]: weights; k = 2 s + h in MFMA step s.
   //   Units 0..17: patch row u, columns 0..31 (row and in-image test scalar, LDS offsets compile-time);
@@ -218,6 +228,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
     // the item loop, where ~20 loop-invariant per-lane values would sit in registers the k loop needs)
     int ln = lane;
     asm volatile("" : "+v"(ln));
+    S4_T(tc0);
     const int l31 = ln & 31, h = ln >> 5;
     const int ch = 32 * ntile + l31;
     const float* cb = c1_s + h * 64 + ch;  // row k = 2 s + h of [9 taps | bias][64]: cb[s * 128]
@@ -237,6 +248,12 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
       d = mfma32(h ? a1 : a0, cb[s * 128], d);
     }
     const float sc = c1_s[640 + ch], sh = c1_s[704 + ch];
+#if S4_DIAG & 1
+    float probe_ = fmaxf(d[0], 0.f);  // waits for the last MFMA
+    asm volatile("" : "+v"(probe_));
+    S4_T(tc1);
+    dg[8] += tc1 - tc0;
+#endif
     float* dst = (l31 & 16) ? dst_hi : dst_lo;  // channels 16..31 of the unit belong to the second chunk
     const int c16 = l31 & 15;
     const int cofs = (c16 >> 3) * S4_PLANE + (c16 & 1), cpr = (c16 >> 1) & 3;
@@ -250,6 +267,9 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int rr = (r & 3) + 8 * (r >> 2);
+#if S4_DIAG & 2  // ablation: no conv1a stores (wrong results)
+          if (d[r] == 12345.678f)
+#endif
           o[((rr & 3) * 9 + (rr >> 2)) * 8] = fmaxf(d[r], 0.f) * sc + sh;
         }
       } else {
@@ -283,10 +303,6 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
     if (half == phase) conv1a_unit(wave, ntile, y0, x0, dst_lo, dst_hi);
     else if (half == phase + 1 && wave + 12 < 20) conv1a_unit(wave + 12, ntile, y0, x0, dst_lo, dst_hi);
   };
-#if S4_DIAG & 1
-  unsigned long long dg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  const unsigned long long dg_t0 = __builtin_readcyclecounter();
-#endif
   // ---- prologue: the first item's image patch and chunks 0, 1 ----
   int item = blockIdx.x;
   int y0, x0, b;
@@ -304,6 +320,10 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
   __syncthreads();
 
   for (; item < nitems; item += gridDim.x) {
+    S4_T(t_top);
+#if S4_DIAG & 1
+    unsigned long long t_prev = t_top;
+#endif
     const int nitem = item + gridDim.x;
     const bool have_next = nitem < nitems;
     const int nb_ = nitem / per_img, nt_ = nitem - nb_ * per_img;
@@ -327,6 +347,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
       S4_T(te);
 #if S4_DIAG & 1
       unsigned long long cv_cycles = 0;
+      dg[0] += te - t_prev;  // item head and chunk seams
 #endif
 #pragma unroll 1
       for (int half = 0; half < 4; ++half) {  // (not unrolled: one copy of the conv1a code and of the half k group)
@@ -334,7 +355,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
         // conv1a, staggered over the three waves of a SIMD (one of them transforms pixels while the other two keep
         // the matrix pipe busy): chunk 1 -> this item's chunks 2, 3 (buffers A, C); chunk 3 -> the next item's
         // chunks 0, 1 (buffers A, B)
-        if ((c & 1) && (c == 1 || have_next)) {
+        if ((c & 1) && (c == 1 || have_next) && !(S4_DIAG & 4)) {
           S4_T(tu);
           conv1a_at_half(half, c == 1 ? 1 : 0, c == 1 ? y0 : ny0, c == 1 ? x0 : nx0, bufA, c == 1 ? bufC : bufB);
 #if S4_DIAG & 1
@@ -344,11 +365,12 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
         // (scheduling fences: hipcc otherwise issues all 36 / 48 reads of a half -- or of several halves -- up front,
         // and with 108 of the 168 registers holding accumulators and filter fragments that spills)
         __builtin_amdgcn_sched_barrier(0);
+        S4_T(tha);
         // this half's filter fragments: requested here, consumed after the transforms below (~1.5 k cycles later);
         // they are live neither during conv1a above nor during the epilogue (register budget)
         float2 bq[6];
 #pragma unroll
-        for (int nu = 0; nu < 6; ++nu) bq[nu] = bfrag(4 * c + half, nu);
+        for (int nu = 0; nu < 6; ++nu) bq[nu] = (S4_DIAG & 16) ? make_float2(1.f + nu, 0.5f) : bfrag(4 * c + half, nu);
         const float* pl = ps + g * S4_PLANE;
         const float* pA = pl + (offA ^ (2 * hh));
         const float* pB = pl + (offB ^ (2 * hh));
@@ -399,6 +421,10 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
           v[4] = v2_fma(-2.f, e31, e42);
           v[5] = v2_fma(-5.f, tr[3], v2_fma(4.f, tr[1], tr[5]));
         }
+#if S4_DIAG & 1
+        asm volatile("" : "+v"(v[0]), "+v"(v[5]));
+        S4_T(thb);
+#endif
 #pragma unroll
         for (int nu = 0; nu < 6; nu += 2) {
           acc[nu] = mfma32(v[nu].x, bq[nu].x, acc[nu]);
@@ -406,12 +432,19 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
           acc[nu] = mfma32(v[nu].y, bq[nu].y, acc[nu]);
           acc[nu + 1] = mfma32(v[nu + 1].y, bq[nu + 1].y, acc[nu + 1]);
         }
+#if S4_DIAG & 1
+        {
+          S4_T(thc);
+          dg[1] += thb - tha; dg[2] += thc - thb;  // transform phase | MFMA issue phase of the half
+        }
+#endif
       }
       S4_T(tg);
       __syncthreads();
       S4_T(th);
 #if S4_DIAG & 1
       dg[3] += cv_cycles; dg[4] += tg - te - cv_cycles; dg[5] += th - tg;
+      t_prev = th;
 #endif
     }
     S4_T(ti);
@@ -426,8 +459,18 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
     asm volatile("" : "+v"(tq));  // (opaque: keeps the reader's index arithmetic out of the item loop's live ranges)
     const int co_q = (tq & 7) * 4, ip2 = (tq >> 3) & 1, tile = tq >> 4;  // reader role (tid < 512)
     const int Ho = a_H >> 1, Wo = a_W >> 1;
+#if S4_DIAG & 32  // ablation: no epilogue; the accumulators stay alive
+    {
+      float sum_ = 0.f;
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum_ += acc[nu][r];
+      if (sum_ == 12345.678f) a_y[tid] = sum_;
+    }
+#endif
 #pragma unroll 1
-    for (int pnt = 0; pnt < 2; ++pnt)  // output-channel tile
+    for (int pnt = 0; pnt < ((S4_DIAG & 32) ? 0 : 2); ++pnt)  // output-channel tile
 #pragma unroll
     for (int jp = 0; jp < 2; ++jp) {   // pooled column inside the Winograd tile = output columns 2 jp, 2 jp + 1
       if (nt == pnt) {
@@ -502,6 +545,7 @@ __global__ __launch_bounds__(S4_THREADS, 1) void stem_wino43_kernel(Stem43Args a
     unsigned long long* o = args.diag + ((size_t)blockIdx.x * 12 + wave) * 16;
     for (int i = 0; i < 8; ++i) o[i] = dg[i];
     o[8] = __builtin_readcyclecounter() - dg_t0;
+    o[9] = dg[8];
   }
 #endif
 }

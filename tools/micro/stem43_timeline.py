@@ -47,11 +47,13 @@ raw.gfc_diag_set_stem43_stamps(None)
 s = stamps.cpu().numpy().astype(np.float64)
 s = s[s[:, 7] > 0]
 n = s[:, 7]
-names = ["img+barrier", "conv1a t0", "barrier", "conv1a t1", "k groups", "chunk barriers", "epilogue"]
+names = ["item head + seams", "half: transform", "half: MFMA issue", "conv1a units", "k groups", "chunk barriers", "epilogue"]
 print(f"stem43: {us:.1f} us per launch; waves {len(s)}, items/wave {np.median(n):.0f}; lifetime/item {np.median(s[:, 8] / n):.0f} cycles; "
       f"MFMA issue per wave and item: {(192 + 10) * 64} cycles (x3 waves per SIMD = {(192 + 10) * 64 * 3})")
 for i, nm in enumerate(names):
     print(f"  {nm:15s} {np.median(s[:, i] / n):8.0f}   (p10 {np.percentile(s[:, i] / n, 10):8.0f}  p90 {np.percentile(s[:, i] / n, 90):8.0f})")
+print(f"  conv1a units: of which LDS reads + the five MFMAs {np.median(s[:, 9] / n):8.0f} (p90 {np.percentile(s[:, 9] / n, 90):8.0f})")
 for xi in range(6):
     sel = s[(np.arange(len(s)) % 12) % 6 == xi]
-    print(f"  xi={xi}: k groups {np.median(sel[:, 4] / sel[:, 7]):8.0f}  chunk barriers {np.median(sel[:, 5] / sel[:, 7]):8.0f}")
+    print(f"  xi={xi}: k groups {np.median(sel[:, 4] / sel[:, 7]):8.0f}  (16 halves: transform {np.median(sel[:, 1] / sel[:, 7]):8.0f}, MFMA issue "
+          f"{np.median(sel[:, 2] / sel[:, 7]):8.0f})  chunk barriers {np.median(sel[:, 5] / sel[:, 7]):8.0f}")
