@@ -411,6 +411,14 @@ def golden_boat_native():
                 "matching_scores0", "matching_scores1"):
         out[key] = npy(pred[key])
     print("boat native", out["image0"].shape, "matches", int((pred["matches0"] >= 0).sum()))
+    # the same pair with filter_threshold 0 (every mutual arg-max pair is a match): with name-seeded weights no score of
+    # this pair reaches 0.1, so the run above pins key points and scores but an EMPTY match set
+    pipe0 = TwoViewPipeline({**conf, "matcher": {**conf["matcher"], "filter_threshold": 0.0}}).eval()
+    pipe0.matcher.load_state_dict(weights.lightglue_state_dict(0), strict=False)
+    pred0 = pipe0(views)
+    for key in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+        out["th0_" + key] = npy(pred0[key])
+    print("boat native, filter_threshold 0: matches", int((pred0["matches0"] >= 0).sum()))
     save("boat_native", **out)
 
 

@@ -557,6 +557,20 @@ def test_boat_pair_native_size_golden(golden):
         assert maxerr(pred["matching_scores" + i][0].cpu()[perm], g["matching_scores" + i][0]) < TOL
     assert match_pairs(pred["keypoints0"][0], pred["keypoints1"][0], pred["matches0"][0]) == \
         match_pairs(g["keypoints0"][0], g["keypoints1"][0], g["matches0"][0])
+    # the same pair with filter_threshold 0 (round 3: the match set above is empty with name-seeded weights, this one is
+    # not): the reference's matched coordinate pairs, and their scores
+    pipe0 = TwoViewPipeline({**conf, "matcher": {**conf["matcher"], "filter_threshold": 0.0}}).eval().to(DEV)
+    pred0 = pipe0(views)
+    ref_pairs = match_pairs(g["keypoints0"][0], g["keypoints1"][0], g["th0_matches0"][0])
+    assert len(ref_pairs) >= 5
+    assert match_pairs(pred0["keypoints0"][0], pred0["keypoints1"][0], pred0["matches0"][0]) == ref_pairs
+    assert match_pairs(pred0["keypoints1"][0], pred0["keypoints0"][0], pred0["matches1"][0]) == \
+        match_pairs(g["keypoints1"][0], g["keypoints0"][0], g["th0_matches1"][0])
+    for i in "01":
+        kp, ref = pred0["keypoints" + i][0].cpu(), g["keypoints" + i][0]
+        order = {tuple(q): j for j, q in enumerate(kp.tolist())}
+        perm = torch.tensor([order[tuple(q)] for q in ref.tolist()])
+        assert maxerr(pred0["matching_scores" + i][0].cpu()[perm], g["th0_matching_scores" + i][0]) < TOL
 
 
 # ---------------------------------------------------------------- full size (BASELINE C2)

@@ -239,3 +239,27 @@ def test_disk_oracle_known_answers():
     dense[:, 2, 2] = torch.tensor([3.0, 0.0, 4.0, 0.0])
     d = odisk.merge_with_descriptors(torch.tensor([[2, 2], [0, 0]]), dense)
     assert torch.allclose(d[0], torch.tensor([0.6, 0.0, 0.8, 0.0])) and (d[1] == 0).all()
+
+
+def test_boat_pair_native_size(golden):
+    """BASELINE config 1 on the oracle: assets/boat1.png <-> boat2.png at 850 x 680 (the reference's TwoViewPipeline on
+    its CPU path produced the vectors): key points bit-exact, scores <= 1e-5, the (empty) match set at filter_threshold
+    0.1 and the 10 mutual matches at filter_threshold 0."""
+    g = golden("boat_native")
+    sd = weights.superpoint_open_state_dict(0)
+    feats = []
+    for i in "01":
+        img = (g["image" + i].float() / 255).permute(2, 0, 1)[None].contiguous()
+        o = osp.extract(sd, img, "open", nms_radius=3, max_num_keypoints=1024, detection_threshold=0.0)
+        assert torch.equal(o["keypoints"][0], g["keypoints" + i][0])
+        close(o["keypoint_scores"][0], g["keypoint_scores" + i][0], 1e-6)
+        feats.append(o)
+    size = torch.tensor([[850.0, 680.0]])
+    args = (weights.lightglue_state_dict(0), torch.stack(feats[0]["keypoints"]), torch.stack(feats[1]["keypoints"]),
+            torch.stack(feats[0]["descriptors"]), torch.stack(feats[1]["descriptors"]), size, size)
+    for th, tag in ((0.1, ""), (0.0, "th0_")):
+        out = olg.match(*args, filter_threshold=th)
+        assert torch.equal(out["matches0"], g[tag + "matches0"]) and torch.equal(out["matches1"], g[tag + "matches1"])
+        close(out["matching_scores0"], g[tag + "matching_scores0"])
+        close(out["matching_scores1"], g[tag + "matching_scores1"])
+    assert int((g["matches0"] >= 0).sum()) == 0 and int((g["th0_matches0"] >= 0).sum()) == 10
