@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
           for (int nt = 0; nt < 4; ++nt) {
             float y = (acc[mt][nt][r] - mu[mt][r]) * rs[j] * ga[nt] + be[nt];
 #if !defined(GW_DIAG) || GW_DIAG < 1  // diagnostic builds (tools/ab_build.sh): 1 = no erf, 2 = no store either
-            y = 0.5f * y * (1.f + gfc_erff(y * 0.70710678118654752440f));
+            y = gfc_gelu(y);
 #endif
 #if !defined(GW_DIAG) || GW_DIAG < 2
             yp[nt * 32] = y;

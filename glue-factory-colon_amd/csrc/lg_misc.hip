@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void layernorm_gelu_kernel(float* __restrict__
     float y[4] = {(v[i].x - mean) * rstd * g.x + bb.x, (v[i].y - mean) * rstd * g.y + bb.y,
                   (v[i].z - mean) * rstd * g.z + bb.z, (v[i].w - mean) * rstd * g.w + bb.w};
 #pragma unroll
-    for (int j = 0; j < 4; ++j) y[j] = 0.5f * y[j] * (1.f + gfc_erff(y[j] * 0.70710678118654752440f));
+    for (int j = 0; j < 4; ++j) y[j] = gfc_gelu(y[j]);
     *reinterpret_cast<float4*>(p + c0) = make_float4(y[0], y[1], y[2], y[3]);
   }
 }
