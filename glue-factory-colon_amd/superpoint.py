@@ -122,6 +122,9 @@ class SuperPoint(BaseModel):
     def forward_pair(self, data0, data1):
         """Both views of an image pair through ONE extractor call when their images agree in shape (see
         superpoint_open.SuperPoint.forward_pair).  Returns (pred0, pred1), each exactly what `self(view)` returns."""
+        for d in (data0, data1):  # what BaseModel.forward checks for a single view (base_model.py:101-113)
+            for key in self.required_data_keys:
+                assert key in d, f"Missing key {key} in data"
         joint = joint_pair_data(data0, data1) if conf_get(self.conf, "sparse_outputs") else None
         if joint is None:
             return self(data0), self(data1)

@@ -125,6 +125,9 @@ class SuperPoint(BaseModel):
         used by TwoViewPipeline: at batch 1 the layers after the stem fill a fraction of the chip, two images
         fill twice as much; the two descriptor arrays also come out adjacent in memory, which the matcher reads
         without a copy).  Returns (pred0, pred1), each exactly what `self(view)` returns."""
+        for d in (data0, data1):  # what BaseModel.forward checks for a single view (base_model.py:101-113)
+            for key in self.required_data_keys:
+                assert key in d, f"Missing key {key} in data"
         joint = joint_pair_data(data0, data1)
         if joint is None:
             return self(data0), self(data1)
