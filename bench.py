@@ -148,31 +148,35 @@ def torch_eager_same_gpu(dev, n_pairs: int = 16, iters: int = 4):
 def batch1_latency(dev, n_pairs: int = 24, warmup: int = 4):
     """Information only (never `value`): the batch-1 regime of the HPatches evaluation loop (config 3: image sizes differ,
     so pairs cannot be batched; datasets/hpatches.py:60) -- one VGA pair at a time through TwoViewPipeline on one
-    stream, device-synchronised wall clock per pair."""
+    stream, with the reference's per-call profiling (device-synchronised timing of extractor and matcher,
+    two_view_pipeline.py:78-102) and without it (`profile_calls: false`)."""
     from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
 
-    pipe = TwoViewPipeline({
-        "extractor": {"name": "extractors.superpoint_open", "weights": "synthetic", "max_num_keypoints": K,
-                      "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True},
-        "matcher": {"name": "matchers.lightglue", "weights": "synthetic", "filter_threshold": 0.1},
-    }).eval().to(dev)
     v0, v1 = synthetic.synthetic_pairs(n_pairs, H, W, seed=4321, device=dev)
     size = torch.tensor([[float(W), float(H)]], device=dev)
     pairs = [{"view0": {"image": v0[i:i + 1], "image_size": size}, "view1": {"image": v1[i:i + 1], "image_size": size}}
              for i in range(n_pairs)]
-    with torch.no_grad():
-        for i in range(warmup):
-            pipe(pairs[i % n_pairs])
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for d in pairs:
-            pred = pipe(d)
-        torch.cuda.synchronize(dev)
-        dt = time.perf_counter() - t0
-    return {"pairs_per_s": round(n_pairs / dt, 1), "ms_per_pair": round(dt / n_pairs * 1e3, 3), "workers": 1,
-            "mode": getattr(pipe, "batch1_mode", "sequential"),
+    res = {}
+    for profiled in (True, False):
+        pipe = TwoViewPipeline({
+            "extractor": {"name": "extractors.superpoint_open", "weights": "synthetic", "max_num_keypoints": K,
+                          "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True},
+            "matcher": {"name": "matchers.lightglue", "weights": "synthetic", "filter_threshold": 0.1},
+            "profile_calls": profiled}).eval().to(dev)
+        with torch.no_grad():
+            for i in range(warmup):
+                pipe(pairs[i % n_pairs])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for d in pairs:
+                pred = pipe(d)
+            torch.cuda.synchronize(dev)
+            res[profiled] = (time.perf_counter() - t0) / n_pairs
+    return {"pairs_per_s": round(1.0 / res[True], 1), "ms_per_pair": round(res[True] * 1e3, 3), "workers": 1,
+            "ms_per_pair_unprofiled": round(res[False] * 1e3, 3), "pairs_per_s_unprofiled": round(1.0 / res[False], 1),
             "matches_last_pair": int((pred["matches0"] >= 0).sum()),
-            "sample": f"{n_pairs} VGA pairs, 1024 kpts, one at a time through TwoViewPipeline on one stream"}
+            "sample": f"{n_pairs} VGA pairs, 1024 kpts, one at a time through TwoViewPipeline on one stream (both views in "
+                      "one extractor call); `unprofiled` = without the reference's per-call device synchronisations"}
 
 
 def conv_mode_of(arg):

@@ -31,6 +31,10 @@ class TwoViewPipeline(BaseModel):
         # MI355X addition: extract both views with ONE extractor call when their images agree in shape and the
         # extractor offers `forward_pair` (same results; `extractor_time_ms` is then the time of that one call)
         "joint_extraction": True,
+        # MI355X addition: False skips the reference's per-call profiling (device synchronisation before and after the
+        # extractor and the matcher plus the peak-memory bookkeeping, two_view_pipeline.py:78-102) and with it the
+        # optional timing / memory keys of the prediction: the pair then runs without a host stall between its stages
+        "profile_calls": True,
     }
     required_data_keys = ["view0", "view1"]
     strict_conf = False
@@ -58,10 +62,11 @@ class TwoViewPipeline(BaseModel):
                 ok = ok and bool(m.is_initialized())
         return ok
 
-    @staticmethod
-    def _timed(device, fn):
+    def _timed(self, device, fn):
         """two_view_pipeline.py:78-102: device-synchronised wall clock + peak-memory delta."""
         mem = None
+        if not conf_get(self.conf, "profile_calls", True):
+            return fn(), None, None
         if device.type == "cuda":
             # the calling thread's stream (= the whole device in the reference's single-stream use); several export
             # workers time their own pairs without serialising each other (their memory figures then overlap)

@@ -755,6 +755,20 @@ def test_two_view_joint_extraction_equals_sequential(variant, threshold, k):
         assert torch.equal(pj[key], ps[key]), key
 
 
+def test_pipeline_without_call_profiling():
+    """`profile_calls: false`: no device synchronisation between the stages and no timing / memory keys (they are optional
+    for the evaluation, eval/hpatches.py:64-87); every other prediction tensor identical."""
+    v0, v1 = synthetic.synthetic_pairs(1, 160, 208, seed=11)
+    size = torch.tensor([[208.0, 160.0]], device=DEV)
+    data = {"view0": {"image": v0.to(DEV), "image_size": size}, "view1": {"image": v1.to(DEV), "image_size": size}}
+    pa = TwoViewPipeline(PIPE_CONF).eval().to(DEV)(data)
+    pb = TwoViewPipeline({**PIPE_CONF, "profile_calls": False}).eval().to(DEV)(data)
+    assert "extractor_time_ms" in pa and "matcher_time_ms" in pa and "total_time_ms" in pa
+    assert not any(k.endswith("_ms") or k.endswith("_mb") for k in pb)
+    for key in pb:
+        assert torch.equal(pa[key], pb[key]), key
+
+
 def test_forward_pair_batched_views():
     """forward_pair with b = 2 images per view (force_num_keypoints): the two halves of one 4-image call equal two
     2-image calls."""
