@@ -283,6 +283,7 @@ def rehearse_cpu(args):
     rank, world, _ = sharding.init_from_env("gloo")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    host_group = torch.distributed.new_group(backend="gloo") if world > 1 else None  # as main(): the closing barrier
     b = args.pairs
     pred = {"matches0": torch.full((b, K), -1, dtype=torch.long), "matching_scores0": torch.zeros(b, K),
             "keypoints0": torch.zeros(b, K, 2), "keypoints1": torch.zeros(b, K, 2)}
@@ -310,7 +311,7 @@ def rehearse_cpu(args):
                           "matches_per_rank": [int(v) for v in allrec[::b, 0].tolist()],
                           "cpu_baseline": base}), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        torch.distributed.barrier(group=host_group)
         torch.distributed.destroy_process_group()
 
 
@@ -359,6 +360,9 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     nat.lib()  # fail loudly if the HIP library is missing
+    # closing synchronisation on the HOST (gloo): rank 0 spends ~a minute after the timed region on its CPU baseline and
+    # checks; behind an RCCL barrier the other ranks' GPUs would spin in a collective kernel for that long
+    host_group = torch.distributed.new_group(backend="gloo") if world > 1 else None
 
     ext = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K, "detection_threshold": 0.0,
                                       "nms_radius": 3, "force_num_keypoints": True,
@@ -619,7 +623,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
     if world > 1:
-        torch.distributed.barrier()
+        torch.distributed.barrier(group=host_group)
         torch.distributed.destroy_process_group()
 
 
