@@ -52,6 +52,54 @@ def run(n_cases=60, seed=2024):
     print("winograd: worst", worst, "bad", bad)
     failures = list(bad)
 
+    # ---- the fused stems (conv1a + conv1b + pool): F(2x2,3x3) and F(4x4,3x3), any H x W, a guard band behind the output ----
+    bad, worst = [], 0.0
+    for case in range(n_cases):
+        h, w, b, bn = ri(2, 150), ri(2, 150), ri(1, 4), ri(0, 1)
+        if case % 7 == 0:
+            b = ri(10, 40)  # more items than workgroups of the persistent F(4,3) launch at small sizes
+            h, w = ri(2, 40), ri(2, 70)
+        img = torch.rand((b, 1, h, w), generator=g)
+        w1 = torch.randn((64, 1, 3, 3), generator=g) / 3
+        b1 = torch.randn((64,), generator=g) * 0.1
+        w2 = torch.randn((64, 64, 3, 3), generator=g) / 24
+        b2 = torch.randn((64,), generator=g) * 0.1
+        s1 = s2 = t1 = t2 = None
+        ref = F.relu(F.conv2d(img.double(), w1.double(), b1.double(), padding=1))
+        if bn:
+            s1, t1 = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+            s2, t2 = torch.rand((64,), generator=g) + 0.5, torch.randn((64,), generator=g) * 0.1
+            s2[::3] *= -1
+            ref = ref * s1.double()[None, :, None, None] + t1.double()[None, :, None, None]
+        ref = F.relu(F.conv2d(ref, w2.double(), b2.double(), padding=1))
+        if bn:
+            ref = ref * s2.double()[None, :, None, None] + t2.double()[None, :, None, None]
+        ref = F.max_pool2d(ref, 2, 2)
+        dd = lambda t: None if t is None else t.to(DEV).contiguous()  # noqa: E731
+        keep = [dd(t) for t in (img.reshape(b, h, w), w1.reshape(64, 9).t(), b1, s1, t1, w2, b2, s2, t2)]
+        n_out = b * (h // 2) * (w // 2) * 64
+        for variant in ("f23", "f43"):
+            if variant == "f23":
+                w2w = torch.empty((16 * 64 * 64,), device=DEV)
+                nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(keep[5]), nat.ptr(w2w), 64, 64, st), "pack")
+                fn = lib.gfc_sp_stem_wino
+            else:
+                w2w = torch.empty((36 * 64 * 64,), device=DEV)
+                nat.check(lib.gfc_pack_conv3x3_wino43(nat.ptr(keep[5]), nat.ptr(w2w), 64, 64, st), "pack43")
+                fn = lib.gfc_sp_stem_wino43
+            buf = torch.full((n_out + 4096,), float("nan"), device=DEV)
+            nat.check(fn(nat.ptr(keep[0]), nat.ptr(keep[1]), nat.ptr(keep[2]), nat.ptr(keep[3]), nat.ptr(keep[4]), nat.ptr(w2w),
+                         nat.ptr(keep[6]), nat.ptr(keep[7]), nat.ptr(keep[8]), nat.ptr(buf), b, h, w, st), "stem")
+            torch.cuda.synchronize()
+            y = buf[:n_out].view(b, h // 2, w // 2, 64)
+            err = (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item() if n_out else 0.0
+            guard_clean = bool(torch.isnan(buf[n_out:]).all())
+            worst = max(worst, err if err == err else 0.0)
+            if not (err < 4e-5 and guard_clean):
+                bad.append(("stem", variant, h, w, b, bn, err, guard_clean))
+    print("stems: worst", worst, "bad", bad)
+    failures += bad
+
     bad = []
     for case in range(n_cases):
         h, w, b = ri(1, 90), ri(1, 90), ri(1, 3)
