@@ -327,6 +327,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
   __shared__ unsigned int sh_cnt;
   __shared__ unsigned long long sh_prefix;
   __shared__ unsigned int sh_remaining;
+  __shared__ unsigned int sh_done;
   const int b = blockIdx.x, tid = threadIdx.x;
   const long long HW = (long long)H * W;
   const float* sb = scores + (size_t)b * HW;
@@ -408,30 +409,47 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const float* __rest
   }
 
   // ---- radix select: find the k-th largest key ----
-  if (tid == 0) { sh_prefix = 0ull; sh_remaining = (unsigned int)k; }
+  // Per pass: a 256-bin histogram of the next byte of the keys that still match the prefix, then the bin that holds the
+  // k-th key -- found by 256 threads (inclusive scan over the bins in descending order; a serial walk by one thread
+  // costs a dependent LDS read per bin, ~10 k cycles per pass).  When the bin's count equals what is still missing, ALL
+  // its keys are winners: k-th = prefix with the lower bytes zero, and the remaining passes are skipped (the low word
+  // is the unique pixel index, so this happens at the latest once the score bytes are through, unless scores tie).
+  if (tid == 0) { sh_prefix = 0ull; sh_remaining = (unsigned int)k; sh_done = 0u; }
   __syncthreads();
   for (int pass = 7; pass >= 0; --pass) {
     const int shift = pass * 8;
     if (tid < 256) hist[tid] = 0;
-    __syncthreads();
     const unsigned long long prefix = sh_prefix;
+    const unsigned int rem = sh_remaining;
+    __syncthreads();
     const unsigned long long himask = (pass == 7) ? 0ull : (~0ull << (shift + 8));
     for (unsigned int i = tid; i < n; i += SEL_THREADS) {
       unsigned long long key = cand[i];
       if ((key & himask) == prefix) atomicAdd(&hist[(unsigned int)(key >> shift) & 0xFF], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned int rem = sh_remaining, acc = 0;
-      int d = 255;
-      for (; d > 0; --d) {
-        if (acc + hist[d] >= rem) break;
-        acc += hist[d];
+    unsigned int v = 0, inc = 0;
+    if (tid < 256) {  // waves 0..3, whole waves
+      v = hist[255 - tid];  // bins in descending order
+      inc = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        unsigned int up = __shfl_up(inc, o);
+        if ((tid & 63) >= o) inc += up;
       }
-      sh_prefix = prefix | ((unsigned long long)d << shift);
-      sh_remaining = rem - acc;
+      if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     }
     __syncthreads();
+    if (tid < 256) {
+      for (int i = 0; i < (tid >> 6); ++i) inc += wsum[i];
+      if (inc >= rem && inc - v < rem) {  // exactly one bin: the first (from the top) whose running count reaches rem
+        sh_prefix = prefix | ((unsigned long long)(255 - tid) << shift);
+        sh_remaining = rem - (inc - v);
+        sh_done = (inc == rem) ? 1u : 0u;
+      }
+    }
+    __syncthreads();
+    if (sh_done) break;  // uniform
   }
   const unsigned long long kth = sh_prefix;  // exactly k keys are >= kth (keys are unique)
   if (tid == 0) sh_cnt = 0;
