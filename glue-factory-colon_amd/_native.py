@@ -116,6 +116,15 @@ SIGNATURES = {
     "gfc_disk_nms_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),
     "gfc_disk_gather_descriptors": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gfc_disk_gather_descriptors_nhwc": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "gfc_disk_conv5x5_packed_floats": (c_size_t, [c_int] * 2),
+    "gfc_disk_pack_conv5x5": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "gfc_disk_conv5x5": (c_int, [c_void_p] * 7 + [c_int] * 8 + [c_void_p]),
+    "gfc_disk_instnorm_workspace_bytes": (c_size_t, [c_int] * 2),
+    "gfc_disk_instnorm_stats": (c_int, [c_void_p] + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gfc_disk_avgpool2": (c_int, [c_void_p] + [c_int] * 5 + [c_void_p, c_void_p]),
+    "gfc_disk_upsample2": (c_int, [c_void_p] + [c_int] * 4 + [c_void_p, c_int, c_void_p]),
+    "gfc_disk_nchw3_to_nhwc4": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p, c_void_p]),
     "gfc_sp_refine_keypoints": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] * 2 + [c_int] * 2 + [c_void_p]),
     "gfc_sp_mask_scores": (c_int, [c_void_p] + [c_int] * 3 + [c_void_p] + [c_int] * 2 + [c_void_p] * 2),
     "gfc_sp_filter_keypoints": (c_int, [c_void_p] * 3 + [c_int] * 2 + [c_void_p] + [c_int] * 2 + [c_void_p, c_float, c_void_p]),

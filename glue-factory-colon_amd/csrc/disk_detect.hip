@@ -179,8 +179,11 @@ extern "C" int gfc_disk_nms_select(const float* heatmap, int B, int H, int W, in
   return GFC_OK;
 }
 
-// descriptors[b, :, y, x] -> out[b, slot, :] / max(||.||, 1e-12); one wave per key point, lanes over channels
+// descriptors[b, :, y, x] -> out[b, slot, :] / max(||.||, 1e-12); one wave per key point, lanes over channels.
+// The dense array is addressed through strides: NCHW (kornia's network: pixel 1, channel H*W) or NHWC (the native
+// network of csrc/disk_unet.hip: pixel D, channel 1 -- one 512-byte row per key point).
 __global__ __launch_bounds__(256) void disk_gather_desc_kernel(const float* __restrict__ dense, int D, int H, int W,
+                                                               long long pix_stride, long long ch_stride,
                                                                const float* __restrict__ kpts,
                                                                const int* __restrict__ counts, int cap,
                                                                float* __restrict__ out) {
@@ -193,22 +196,31 @@ __global__ __launch_bounds__(256) void disk_gather_desc_kernel(const float* __re
     return;
   }
   const int x = (int)kpts[((size_t)b * cap + slot) * 2], y = (int)kpts[((size_t)b * cap + slot) * 2 + 1];
-  const float* src = dense + (size_t)b * D * H * W + (size_t)y * W + x;
+  const float* src = dense + (size_t)b * D * H * W + ((size_t)y * W + x) * pix_stride;
   float ss = 0.f;
   for (int c = lane; c < D; c += 64) {
-    const float v = src[(size_t)c * H * W];
+    const float v = src[(size_t)c * ch_stride];
     ss += v * v;
   }
   ss = wave_sum(ss);
   const float inv = 1.f / fmaxf(sqrtf(ss), 1e-12f);
-  for (int c = lane; c < D; c += 64) o[c] = src[(size_t)c * H * W] * inv;
+  for (int c = lane; c < D; c += 64) o[c] = src[(size_t)c * ch_stride] * inv;
 }
 
 extern "C" int gfc_disk_gather_descriptors(const float* dense_nchw, int B, int D, int H, int W, const float* kpts,
                                            const int32_t* counts, int cap, float* out, void* stream) {
   if (!dense_nchw || !kpts || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || cap <= 0) return GFC_ERR_INVALID;
   hipLaunchKernelGGL(disk_gather_desc_kernel, dim3((cap + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, dense_nchw, D, H,
-                     W, kpts, counts, cap, out);
+                     W, 1ll, (long long)H * W, kpts, counts, cap, out);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+extern "C" int gfc_disk_gather_descriptors_nhwc(const float* dense_nhwc, int B, int D, int H, int W, const float* kpts,
+                                                const int32_t* counts, int cap, float* out, void* stream) {
+  if (!dense_nhwc || !kpts || !out || B <= 0 || D <= 0 || H <= 0 || W <= 0 || cap <= 0) return GFC_ERR_INVALID;
+  hipLaunchKernelGGL(disk_gather_desc_kernel, dim3((cap + 3) / 4, B), dim3(256), 0, (hipStream_t)stream, dense_nhwc, D, H,
+                     W, (long long)D, 1ll, kpts, counts, cap, out);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

@@ -3,30 +3,35 @@
 dictionaries and error behaviour.
 
 The reference delegates ALL arithmetic to the third-party `kornia` package (`kornia.feature.DISK`, unpinned
->= 0.6.12): the U-Net, its pretrained weights ("depth": a download) and the detection functions.  Neither kornia nor
-the weights exist offline, so the network cannot be restated or pinned here.  What this module builds natively is
-everything BEHIND the network, as HIP kernels (csrc/disk_detect.hip), restated from kornia's published source:
+>= 0.6.12): the U-Net, its pretrained weights ("depth": a download) and the detection functions.  kornia does not
+exist offline; both halves are restated from kornia's published source and run as HIP kernels -- PARITY UNPINNED for
+both (no reference run, no reference-held fixture), checked against oracle/disk_unet.py and oracle/disk.py:
 
-    pad to a multiple of 16 (disk_kornia.py:31-35) -> network -> crop -> window-5 NMS + cutoff -> top-n by the
-    (n+1)-th score -> descriptors at the integer pixel, L2-normalised -> specular filter (offset 0.5) ->
-    pad_and_stack -> +0.5                                                    (disk_kornia.py:42-47,84-137)
+    pad to a multiple of 16 (disk_kornia.py:31-35) -> network (disk_unet.py, csrc/disk_unet.hip: thin U-Net of 5x5
+    convolutions on fp32 MFMA) -> crop -> window-5 NMS + cutoff -> top-n by the (n+1)-th score -> descriptors at the
+    integer pixel, L2-normalised -> specular filter (offset 0.5) -> pad_and_stack -> +0.5   (disk_kornia.py:42-47,84-137;
+    csrc/disk_detect.hip)
 
-The network is supplied EXPLICITLY as `dense_fn(images [b,3,H,W]) -> (heat-maps [b,1,H,W], descriptors [b,D,H,W])`
-on the device, passed as `DISK(conf, dense_fn=...)` or `set_dense_fn` (e.g. kornia's
-`DISK.from_pretrained("depth").heatmap_and_dense_descriptors` where that package and its weights exist).  Nothing is
-picked up implicitly: an importable kornia is NOT used by itself (no silent third-party eager network on the product
-path), and without a dense_fn `forward` raises -- there is no substitute network.  NETWORK PARITY UNPINNED; the
-post-network stages are tested against oracle/disk.py.
+Weights: `self.model` carries kornia's parameter names (`model.unet.path_down...`), so a kornia DISK state dict -- or
+the file kornia downloads for "depth", given as a local path -- loads with `load_state_dict`; `weights: "synthetic[:seed]"`
+= name-seeded weights (tests, offline benchmarks).  "depth" itself needs a download: the module then stays
+un-initialised (forward raises) until `load_state_dict` is called.  Nothing third-party is picked up implicitly: an
+importable kornia is NOT used by itself.  A caller who wants another network passes it EXPLICITLY as
+`DISK(conf, dense_fn=...)` / `set_dense_fn` with `dense_fn(images [b,3,H,W]) -> (heat-maps [b,1,H,W], descriptors
+[b,D,H,W])` on the device.
 
     model.extractor.name = glue_factory_colon_amd.disk_kornia
 """
 import time
+from pathlib import Path
 
 import torch
 
 from . import _native as nat
+from . import weights as _weights
 from ._superpoint_common import pad_keypoints_native, specular_mask_bytes
 from .base_model import BaseModel, conf_get
+from .disk_unet import DiskUnet
 
 
 class DISK(BaseModel):
@@ -50,16 +55,24 @@ class DISK(BaseModel):
 
     def _init(self, conf):
         self._ws = nat.Workspace()
-        if self._dense_fn is None:
-            # No network is built into this package (kornia's U-Net source and weights are absent offline, a25 in
-            # DESIGN.md), and kornia's PyTorch network is deliberately NOT picked up even when it is importable: the
-            # product path never runs a third-party eager network silently.  A caller who wants that passes it
-            # explicitly: DISK(conf, dense_fn=kornia.feature.DISK.from_pretrained("depth").heatmap_and_dense_descriptors).
-            return  # not initialised: forward raises until a dense_fn is supplied
-        self.set_initialized()
+        if self._dense_fn is not None:  # an explicitly supplied network replaces the native one
+            self.set_initialized()
+            return
+        self.model = DiskUnet(int(conf_get(conf, "desc_dim")))
+        w = conf_get(conf, "weights")
+        if isinstance(w, str) and w.startswith("synthetic"):
+            seed = int(w.split(":")[1]) if ":" in w else 0
+            self.model.load_state_dict(_weights.disk_state_dict(seed, int(conf_get(conf, "desc_dim"))))
+            self.set_initialized()
+        elif w is not None and Path(str(w)).exists():
+            ckpt = torch.load(str(w), map_location="cpu")
+            self.model.load_state_dict(ckpt.get("extractor", ckpt))  # kornia's files keep the network under "extractor"
+            self.set_initialized()
+        # anything else ("depth", "epipolar": kornia downloads them, disk_kornia.py:25): no network here -- the module
+        # stays un-initialised until load_state_dict() supplies the parameters
 
     def is_initialized(self):
-        return self._dense_fn is not None and bool(self.are_weights_initialized)
+        return bool(self.are_weights_initialized)
 
     def set_dense_fn(self, dense_fn):
         object.__setattr__(self, "_dense_fn", dense_fn)
@@ -67,24 +80,29 @@ class DISK(BaseModel):
 
     def load_state_dict(self, *args, **kwargs):
         ret = super().load_state_dict(*args, **kwargs)
-        if self._dense_fn is not None:
-            self.set_initialized()
+        self.set_initialized()
         return ret
 
     # ---- network boundary: pad to /16, run, crop (disk_kornia.py:29-40) ----
     def _dense(self, images):
+        """-> heat-map [n,h,w] contiguous, dense descriptors contiguous, their layout ("nhwc" native / "nchw" dense_fn)."""
         h, w = images.shape[2:]
         if conf_get(self.conf, "pad_if_not_divisible"):
             pd_h = 16 - h % 16 if h % 16 > 0 else 0
             pd_w = 16 - w % 16 if w % 16 > 0 else 0
-            images = torch.nn.functional.pad(images, (0, pd_w, 0, pd_h), value=0.0)  # plumbing: a zero-filled copy
-        heat, desc = self._dense_fn(images)
-        return heat[..., :h, :w], desc[..., :h, :w]
+            if pd_h or pd_w:
+                images = torch.nn.functional.pad(images, (0, pd_w, 0, pd_h), value=0.0)  # plumbing: a zero-filled copy
+        if self._dense_fn is not None:
+            heat, desc = self._dense_fn(images)
+            return (heat[..., :h, :w].reshape(heat.shape[0], h, w).contiguous().float(),
+                    desc[..., :h, :w].contiguous().float(), "nchw")
+        heat, desc = self.model.dense_nhwc(images)
+        return heat[:, :h, :w].contiguous(), desc[:, :h, :w].contiguous(), "nhwc"
 
     def _forward(self, data):
-        if self._dense_fn is None:
-            raise RuntimeError("DISK: no network available (kornia is not installed and no dense_fn was supplied); "
-                               "the MI355X build provides the stages behind the network only")
+        if not self.are_weights_initialized:
+            raise RuntimeError("DISK: the network has no weights (conf.weights = 'synthetic' or a local file, "
+                               "load_state_dict with kornia's DISK parameters, or an explicit dense_fn); nothing is downloaded")
         conf, lib = self.conf, nat.lib()
         image = data["image"]
         nat.require_cuda(image, "data['image']")
@@ -103,9 +121,7 @@ class DISK(BaseModel):
         with torch.no_grad():
             for i in range(0, b, chunk):  # disk_kornia.py:62-83
                 start = time.perf_counter()
-                heat, dense = self._dense(image[i:i + chunk].float())
-                heat = heat.reshape(heat.shape[0], h, w).contiguous().float()
-                dense = dense.contiguous().float()
+                heat, dense, layout = self._dense(image[i:i + chunk].float())
                 n_i = heat.shape[0]
                 ws = self._ws.get(lib.gfc_disk_select_workspace_bytes(n_i, h, w), dev)
                 nat.check(lib.gfc_disk_nms_select(nat.ptr(heat), n_i, h, w, window, cutoff, -1 if k is None else int(k),
@@ -120,7 +136,8 @@ class DISK(BaseModel):
                 nat.check(lib.gfc_sp_filter_keypoints(nat.ptr(kpts), nat.ptr(ksc), nat.ptr(counts), b, cap, nat.ptr(smask),
                                                       smask.shape[-2], smask.shape[-1], nat.ptr(swh), 0.0, st),
                           "gfc_sp_filter_keypoints")
-            d = int(dense_all[0].shape[1])
+            d = int(dense_all[0].shape[1] if layout == "nchw" else dense_all[0].shape[3])
+            gather = lib.gfc_disk_gather_descriptors if layout == "nchw" else lib.gfc_disk_gather_descriptors_nhwc
             force = conf_get(conf, "force_num_keypoints")
             if force:
                 if k is None:
@@ -141,10 +158,8 @@ class DISK(BaseModel):
             if n_out > 0:
                 for j, i in enumerate(range(0, b, chunk)):  # slots >= count: zeros (pad_and_stack "zeros")
                     dn = dense_all[j]
-                    nat.check(lib.gfc_disk_gather_descriptors(nat.ptr(dn), dn.shape[0], d, h, w,
-                                                              nat.ptr(kpts[i:i + dn.shape[0]]),
-                                                              nat.ptr(counts[i:i + dn.shape[0]]), n_out,
-                                                              nat.ptr(desc[i:i + dn.shape[0]]), st),
+                    nat.check(gather(nat.ptr(dn), dn.shape[0], d, h, w, nat.ptr(kpts[i:i + dn.shape[0]]),
+                                     nat.ptr(counts[i:i + dn.shape[0]]), n_out, nat.ptr(desc[i:i + dn.shape[0]]), st),
                               "gfc_disk_gather_descriptors")
             if force:
                 kpts, ksc = pad_keypoints_native(kpts, ksc, counts, n_out, 0, data, image)  # disk_kornia.py:109-124
@@ -155,7 +170,8 @@ class DISK(BaseModel):
             "extractor_core_time_ms": image.new_full((b,), core_ms / b),
         }
         if conf_get(conf, "dense_outputs"):
-            pred["dense_descriptors"] = torch.cat(dense_all, 0)
+            dense = torch.cat(dense_all, 0)
+            pred["dense_descriptors"] = dense if layout == "nchw" else dense.permute(0, 3, 1, 2)  # [b,D,h,w] either way
         return pred
 
     def loss(self, pred, data):

@@ -194,3 +194,27 @@ def lightglue_adaptive_state_dict(seed: int = 0, gain: float = 8.0, prune_z: flo
         sd[k + ".weight"] = sd[k + ".weight"] * gain
         sd[k + ".bias"] = torch.full_like(sd[k + ".bias"], -2.94 - gain * _MATCH_MEAN[i] + prune_z * gain * _MATCH_STD[i])
     return sd
+
+
+def disk_state_dict(seed: int = 0, desc_dim: int = 128):
+    """kornia.feature.DISK key layout (kornia/feature/disk/_unets: `unet.path_down.<i>.1.{1.weight,3.weight,3.bias}`,
+    `unet.path_up.<i>.conv.{...}`; index 1 = PReLU slopes, 3 = Conv2d; the first down block has no gate), name-seeded.
+    He-scaled 5x5 filters, slopes around PReLU's initial 0.25; the heat-map channel gets a larger gain so that window
+    NMS sees distinct maxima."""
+    sd = OrderedDict()
+    down = (3, 16, 32, 64, 64, 64)
+    for i in range(5):
+        prefix = f"unet.path_down.{i}.1"
+        if i > 0:
+            sd[prefix + ".1.weight"] = _rand(prefix + ".1.weight", seed, (down[i],), 0.1, 0.4)
+        _conv(sd, prefix + ".3", down[i], down[i + 1], 5, seed)
+    up = (64, 64, 64, desc_dim + 1)
+    bot = (64,) + up
+    hor = down[-2::-1]
+    for i in range(4):
+        prefix = f"unet.path_up.{i}.conv"
+        cat = bot[i] + hor[i]
+        sd[prefix + ".1.weight"] = _rand(prefix + ".1.weight", seed, (cat,), 0.1, 0.4)
+        _conv(sd, prefix + ".3", cat, up[i], 5, seed)
+    sd["unet.path_up.3.conv.3.weight"][desc_dim] *= 3.0
+    return sd

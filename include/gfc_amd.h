@@ -272,6 +272,42 @@ int gfc_disk_nms_select(const float* heatmap, int B, int H, int W, int window, f
  * (F.normalize, eps 1e-12) -> out [B,cap,D]; slots >= counts[b] (counts nullable) are zero-filled. */
 int gfc_disk_gather_descriptors(const float* dense_nchw, int B, int D, int H, int W, const float* kpts,
                                 const int32_t* counts, int cap, float* out, void* stream);
+/* the same from an NHWC array [B,H,W,D] (what gfc_disk_conv5x5 writes: one contiguous row per key point) */
+int gfc_disk_gather_descriptors_nhwc(const float* dense_nhwc, int B, int D, int H, int W, const float* kpts,
+                                     const int32_t* counts, int cap, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * DISK network (disk_kornia.py:24-47 -> kornia.feature.DISK.heatmap_and_dense_descriptors): the thin U-Net
+ * Unet(in_features=3, size=5, down=[16,32,64,64,64], up=[64,64,64,desc_dim+1]) of kornia/feature/disk/_unets,
+ * restated from kornia's published source (absent offline: NETWORK PARITY UNPINNED).  Activations are NHWC fp32.
+ * One "Conv" of that network = [InstanceNorm2d -> PReLU ->] Conv2d(5x5, padding 2, bias): the statistics come from
+ * gfc_disk_instnorm_stats, normalisation and gate are applied while gfc_disk_conv5x5 stages its input.
+ * ---------------------------------------------------------------------------------- */
+/* Conv2d weights OIHW [cout][cin][5][5] -> the layout gfc_disk_conv5x5 reads (cin padded to 16, cout to 32). */
+size_t gfc_disk_conv5x5_packed_floats(int cout, int cin);
+int gfc_disk_pack_conv5x5(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
+/* y[b,y,x, 0:co_count] (channel stride ldy >= co_count: a slice of a wider, concatenated tensor) =
+ *   conv5x5(gate(norm(x)))[b,y,x, co_first : co_first + co_count] + bias  of a layer with cout_total output channels
+ * (co_first % 32 == 0; the whole layer: co_first 0, co_count cout_total -- DISK's last layer is run as descriptors
+ * [0,128) and heat-map [128,129) into two arrays);  x [B,H,W,cin] contiguous, cin % 4 == 0 (channels beyond cin of the
+ * last 16-chunk count as zero); mean/rstd [B,cin] (both or neither; InstanceNorm2d without affine), prelu [cin] or
+ * NULL (PReLU slope per channel); zero padding is applied AFTER normalisation and gate, as Conv2d pads its own input.
+ * w_packed / bias are the layer's whole arrays (not offset by the caller). */
+int gfc_disk_conv5x5(const float* x, const float* mean, const float* rstd, const float* prelu, const float* w_packed,
+                     const float* bias, float* y, int ldy, int B, int H, int W, int cin, int cout_total, int co_first,
+                     int co_count, void* stream);
+/* per (image, channel) mean and 1 / sqrt(biased variance + eps) over H x W of x [B,H,W,C] contiguous
+ * (float64 sums, fixed summation order); C in {16, 32, 64, 80, 96, 128} or any C with 480 % (C/4) == 0. */
+size_t gfc_disk_instnorm_workspace_bytes(int B, int C);
+int gfc_disk_instnorm_stats(const float* x, int B, int H, int W, int C, float eps, float* mean, float* rstd, void* ws,
+                            size_t ws_bytes, void* stream);
+/* F.avg_pool2d(x, 2): x [B,H,W,C] with channel stride ldx (H, W even) -> y [B,H/2,W/2,C] contiguous */
+int gfc_disk_avgpool2(const float* x, int ldx, int B, int H, int W, int C, float* y, void* stream);
+/* F.interpolate(scale_factor=2, mode="bilinear", align_corners=False): x [B,h,w,C] contiguous -> the first C
+ * channels of y [B,2h,2w,ldy] */
+int gfc_disk_upsample2(const float* x, int B, int h, int w, int C, float* y, int ldy, void* stream);
+/* image [B,3,H,W] -> [B,H,W,4] (fourth channel zero): the NHWC input of the first convolution */
+int gfc_disk_nchw3_to_nhwc4(const float* image, int B, int H, int W, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LightGlue matcher

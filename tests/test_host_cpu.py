@@ -374,3 +374,35 @@ def test_disk_never_picks_up_a_third_party_network_implicitly(monkeypatch):
         m({"image": torch.zeros(1, 3, 32, 32)})
     m2 = disk_kornia.DISK({"max_num_keypoints": 64}, dense_fn=lambda x: (x[:, :1], x))
     assert m2.is_initialized() and not used
+
+
+def test_disk_network_state_dict_layout_and_checkpoint_file(tmp_path):
+    """Config 5: the native DISK network carries kornia's parameter names (restated: oracle/disk_unet.py), so the module's
+    state dict is `model.` + those keys (gluefactory/models/extractors/disk_kornia.py:24-28 keeps kornia's DISK as
+    `self.model`), name-seeded weights and a kornia-style checkpoint file ({"extractor": state_dict}) load, and "depth"
+    (a download) leaves the module un-initialised."""
+    from glue_factory_colon_amd import disk_kornia, weights
+    from oracle import disk_unet as ounet
+
+    sd = weights.disk_state_dict(3)
+    table = ounet.layer_table(128)
+    assert [r[1:3] for r in table] == [(3, 16), (16, 32), (32, 64), (64, 64), (64, 64), (128, 64), (128, 64), (96, 64), (80, 129)]
+    for prefix, cin, cout, gated in table:
+        assert tuple(sd[prefix + ".3.weight"].shape) == (cout, cin, 5, 5) and tuple(sd[prefix + ".3.bias"].shape) == (cout,)
+        assert (prefix + ".1.weight" in sd) == gated and (not gated or tuple(sd[prefix + ".1.weight"].shape) == (cin,))
+    assert len(sd) == sum(3 if r[3] else 2 for r in table)
+    m = disk_kornia.DISK({"weights": "synthetic:3", "max_num_keypoints": 32})
+    assert m.is_initialized() and set(m.state_dict()) == {"model." + k for k in sd}
+    assert all(torch.equal(m.state_dict()["model." + k], v) for k, v in sd.items())
+    path = tmp_path / "disk_depth.ckpt"
+    torch.save({"extractor": sd}, str(path))
+    m2 = disk_kornia.DISK({"weights": str(path)})
+    assert m2.is_initialized() and torch.equal(m2.state_dict()["model.unet.path_up.3.conv.3.bias"], sd["unet.path_up.3.conv.3.bias"])
+    m3 = disk_kornia.DISK({})  # "depth"
+    assert not m3.is_initialized()
+    m3.load_state_dict(m.state_dict())
+    assert m3.is_initialized()
+    out = ounet.heatmap_and_dense_descriptors(sd, torch.rand(1, 3, 32, 48))
+    assert out[0].shape == (1, 1, 32, 48) and out[1].shape == (1, 128, 32, 48)
+    with pytest.raises(ValueError, match="divisible by 16"):
+        ounet.unet(sd, torch.rand(1, 3, 30, 48))
