@@ -11,7 +11,7 @@
 //        clipped to the first n
 //     -> descriptors read at the integer pixel, L2-normalised over D (F.normalize, eps 1e-12).
 // HBM-bound byte / index work: coalesced row reads, LDS halo tile for the window test, one workgroup per image for
-// the (sequential) order-preserving compaction.
+// the order-preserving compaction (wave-contiguous segments of the map, then a compact survivor list).
 #include "common.h"
 
 __device__ __forceinline__ unsigned int dk_order_bits(float f) {
@@ -60,90 +60,142 @@ __global__ __launch_bounds__(256) void disk_nms_kernel(const float* __restrict__
   }
 }
 
-// one workgroup (1024 threads) per image: count the survivors, radix-select the threshold, ordered compaction
+// One workgroup (1024 threads = 16 waves) per image.  The dense survivor map is read TWICE, by wave-contiguous segments
+// with eight independent loads in flight per lane (a single workgroup streaming 1.2 MB with one load per wave in
+// flight is latency-bound: 0.13 ms per VGA image in the first version, whose compaction also took three workgroup
+// barriers per 1024 pixels): pass 1 counts the survivors of each wave's segment, pass 2 writes them -- in row-major
+// order, because the segments are contiguous and ordered -- to a compact (index, score) list.  Everything after that
+// (radix select of the threshold, the final ordered filter) walks the list, a few thousand entries.
+#define DKS_U 8
 __global__ __launch_bounds__(1024) void disk_select_kernel(const float* __restrict__ cand, int H, int W, int n, int cap,
                                                            float* __restrict__ kpts, float* __restrict__ kscores,
-                                                           int* __restrict__ counts) {
+                                                           int* __restrict__ counts, int* __restrict__ list_idx_all,
+                                                           float* __restrict__ list_sc_all) {
   __shared__ unsigned int hist[256];
-  __shared__ unsigned int s_prefix, s_want, s_total;
-  __shared__ int wave_sums[16];
+  __shared__ unsigned int s_prefix, s_want;
+  __shared__ unsigned int wsum[16];
+  __shared__ int wave_cnt[16];
   __shared__ int s_base;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const float* src = cand + (size_t)b * H * W;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int total = H * W;
-  // survivors
+  const float* src = cand + (size_t)b * total;
+  int* list_idx = list_idx_all + (size_t)b * total;
+  float* list_sc = list_sc_all + (size_t)b * total;
+  // ---- pass 1: survivors per wave segment ----
+  const int seg = (((total + 15) / 16) + 63) & ~63;
+  const int s0 = wave * seg, s1 = min(s0 + seg, total);
   int c = 0;
-  for (int i = tid; i < total; i += 1024) c += src[i] > -INFINITY;
-  if (tid == 0) s_total = 0;
+  for (int i0 = s0; i0 < s1; i0 += 64 * DKS_U) {
+    float v[DKS_U];
+#pragma unroll
+    for (int u = 0; u < DKS_U; ++u) {
+      const int i = i0 + u * 64 + lane;
+      v[u] = i < s1 ? src[i] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < DKS_U; ++u) c += __popcll(__ballot(v[u] > -INFINITY));
+  }
+  if (lane == 0) wave_cnt[wave] = c;
   __syncthreads();
-  atomicAdd(&s_total, (unsigned int)c);  // integer count: order-independent
+  int base = 0, count = 0;
+  for (int w = 0; w < 16; ++w) {
+    const int t = wave_cnt[w];
+    if (w < wave) base += t;
+    count += t;
+  }
+  // ---- pass 2: the ordered survivor list ----
+  for (int i0 = s0; i0 < s1; i0 += 64 * DKS_U) {
+    float v[DKS_U];
+#pragma unroll
+    for (int u = 0; u < DKS_U; ++u) {
+      const int i = i0 + u * 64 + lane;
+      v[u] = i < s1 ? src[i] : -INFINITY;
+    }
+#pragma unroll
+    for (int u = 0; u < DKS_U; ++u) {
+      const bool keep = v[u] > -INFINITY;
+      const unsigned long long bal = __ballot(keep);
+      if (keep) {
+        const int slot = base + __popcll(bal & ((1ull << lane) - 1ull));
+        list_idx[slot] = i0 + u * 64 + lane;
+        list_sc[slot] = v[u];
+      }
+      base += __popcll(bal);
+    }
+  }
+  __threadfence();
   __syncthreads();
-  const int count = (int)s_total;
   float thr = -INFINITY;  // keep score > thr
   bool drop_all = false;
   if (n >= 0) {
     if (count == 0) {
       drop_all = true;  // (torch.kthvalue on an empty tensor raises in the reference; nothing to return either way)
     } else {
-      // threshold = the k-th largest survivor, k = min(n + 1, count): MSB-first radix select on the order bits
-      unsigned int prefix = 0, want = (unsigned int)min(n + 1, count);
+      // threshold = the k-th largest survivor, k = min(n + 1, count): MSB-first radix select on the order bits; the
+      // bin that holds it is found by a 256-thread scan (all four passes run: the threshold is an exact score)
+      if (tid == 0) { s_prefix = 0u; s_want = (unsigned int)min(n + 1, count); }
+      __syncthreads();
       for (int shift = 24; shift >= 0; shift -= 8) {
         if (tid < 256) hist[tid] = 0;
+        const unsigned int prefix = s_prefix, want = s_want;
         __syncthreads();
         const unsigned int hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int i = tid; i < total; i += 1024) {
-          const float v = src[i];
-          if (v > -INFINITY) {
-            const unsigned int o = dk_order_bits(v);
-            if ((o & hi_mask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
-          }
+        for (int i = tid; i < count; i += 1024) {
+          const unsigned int o = dk_order_bits(list_sc[i]);
+          if ((o & hi_mask) == prefix) atomicAdd(&hist[(o >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-          unsigned int acc = 0;
-          int d = 255;
-          for (; d > 0; --d) {
-            if (acc + hist[d] >= want) break;
-            acc += hist[d];
+        unsigned int hv = 0, inc = 0;
+        if (tid < 256) {  // waves 0..3, whole waves; bins in descending order
+          hv = hist[255 - tid];
+          inc = hv;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const unsigned int up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
           }
-          s_prefix = prefix | ((unsigned int)d << shift);
-          s_want = want - acc;
+          if (lane == 63) wsum[wave] = inc;
         }
         __syncthreads();
-        prefix = s_prefix;
-        want = s_want;
+        if (tid < 256) {
+          for (int i = 0; i < wave; ++i) inc += wsum[i];
+          if (inc >= want && inc - hv < want) {  // the first bin from the top whose running count reaches `want`
+            s_prefix = prefix | ((unsigned int)(255 - tid) << shift);
+            s_want = want - (inc - hv);
+          }
+        }
         __syncthreads();
       }
-      thr = dk_from_order_bits(prefix);
+      thr = dk_from_order_bits(s_prefix);
     }
   }
-  // ordered compaction of {score > thr} in row-major order, clipped to the first `lim`
+  // ---- ordered filter of the list: {score > thr} in row-major order, clipped to the first `lim` ----
   const int lim = n >= 0 ? min(n, cap) : cap;
   if (tid == 0) s_base = 0;
   __syncthreads();
-  const int lane = tid & 63, wave = tid >> 6;
-  for (int i0 = 0; i0 < total; i0 += 1024) {
+  for (int i0 = 0; i0 < count; i0 += 1024) {
     const int i = i0 + tid;
-    const float v = i < total ? src[i] : -INFINITY;
-    const bool keep = !drop_all && v > -INFINITY && v > thr;
+    const float v = i < count ? list_sc[i] : -INFINITY;
+    const bool keep = !drop_all && i < count && v > thr;
     const unsigned long long bal = __ballot(keep);
     const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_sums[wave] = __popcll(bal);
+    if (lane == 0) wave_cnt[wave] = __popcll(bal);
     __syncthreads();
-    int off = s_base;
-    for (int w = 0; w < wave; ++w) off += wave_sums[w];
+    int off = s_base, all = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int t = wave_cnt[w];
+      if (w < wave) off += t;
+      all += t;
+    }
     const int slot = off + in_wave;
     if (keep && slot < lim) {
-      kpts[((size_t)b * cap + slot) * 2] = (float)(i % W);
-      kpts[((size_t)b * cap + slot) * 2 + 1] = (float)(i / W);
+      const int idx = list_idx[i];
+      kpts[((size_t)b * cap + slot) * 2] = (float)(idx % W);
+      kpts[((size_t)b * cap + slot) * 2 + 1] = (float)(idx / W);
       kscores[(size_t)b * cap + slot] = v;
     }
     __syncthreads();
-    if (tid == 0) {
-      int s = 0;
-      for (int w = 0; w < 16; ++w) s += wave_sums[w];
-      s_base += s;
-    }
+    if (tid == 0) s_base += all;
     __syncthreads();
     if (s_base >= lim) break;  // uniform
   }
@@ -152,7 +204,7 @@ __global__ __launch_bounds__(1024) void disk_select_kernel(const float* __restri
 
 extern "C" size_t gfc_disk_select_workspace_bytes(int B, int H, int W) {
   if (B <= 0 || H <= 0 || W <= 0) return 0;
-  return gfc_align((size_t)B * H * W * sizeof(float));
+  return 3 * gfc_align((size_t)B * H * W * sizeof(float));  // survivor map, survivor list (index, score)
 }
 
 extern "C" int gfc_disk_nms_select(const float* heatmap, int B, int H, int W, int window, float cutoff, int n, int cap,
@@ -174,7 +226,11 @@ extern "C" int gfc_disk_nms_select(const float* heatmap, int B, int H, int W, in
     case 9: hipLaunchKernelGGL(disk_nms_kernel<4>, grid, dim3(256), 0, st, heatmap, H, W, cutoff, cand); break;
     default: return GFC_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(disk_select_kernel, dim3(B), dim3(1024), 0, st, cand, H, W, n, cap, kpts, kscores, counts);
+  const size_t plane = gfc_align((size_t)B * H * W * sizeof(float));
+  int* list_idx = reinterpret_cast<int*>((char*)ws + plane);
+  float* list_sc = reinterpret_cast<float*>((char*)ws + 2 * plane);
+  hipLaunchKernelGGL(disk_select_kernel, dim3(B), dim3(1024), 0, st, cand, H, W, n, cap, kpts, kscores, counts, list_idx,
+                     list_sc);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

@@ -181,6 +181,68 @@ __global__ __launch_bounds__(256, 2) void disk_conv5x5_kernel(Disk5Args a) {
   }
 }
 
+// One output channel (DISK's heat-map: channel 128 of the last layer).  A matrix-VECTOR product per pixel: on the MFMA
+// kernel it costs a 32-wide block for one column (0.33 ms of the 2.2 ms network per VGA image); here one thread owns
+// one pixel of the 16x16 tile, the patch is staged exactly as above (normalised + gated, pitch 20: conflict-free
+// ds_read_b128 across 16 consecutive pixels) and the 25 x 16 weights of a chunk are wave-uniform scalar loads.
+__global__ __launch_bounds__(256) void disk_conv5x5_c1_kernel(Disk5Args a) {
+  __shared__ __attribute__((aligned(16))) float in_s[DH * DH * DLD];
+  const int tid = threadIdx.x;
+  int t = blockIdx.x;
+  const int x0 = (t % a.tiles_x) * DT;
+  t /= a.tiles_x;
+  const int y0 = (t % a.tiles_y) * DT;
+  const int b = t / a.tiles_y;
+  const float* xin = a.x + (size_t)b * a.H * a.W * a.cin;
+  const int c4 = (tid & 3) * 4;
+  const int py = tid >> 4, px = tid & 15;
+  float acc = 0.f;
+  for (int chunk = 0; chunk < a.chunks; ++chunk) {
+    const int c = chunk * DKC + c4;
+    const bool cvalid = c < a.cin;
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = make_float4(1.f, 1.f, 1.f, 1.f), sl = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (cvalid && a.mean) {
+      mu = *reinterpret_cast<const float4*>(a.mean + (size_t)b * a.cin + c);
+      rs = *reinterpret_cast<const float4*>(a.rstd + (size_t)b * a.cin + c);
+    }
+    if (cvalid && a.prelu) sl = *reinterpret_cast<const float4*>(a.prelu + c);
+    if (chunk) __syncthreads();  // every thread is through with the previous chunk's patch
+#pragma unroll
+    for (int i = 0; i < (DH * DH * 4 + 255) / 256; ++i) {
+      const int idx = tid + 256 * i;
+      const int p = idx >> 2;
+      if (p >= DH * DH) break;
+      const int gy = y0 - 2 + p / DH, gx = x0 - 2 + p % DH;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cvalid && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) {
+        v = *reinterpret_cast<const float4*>(xin + ((size_t)gy * a.W + gx) * a.cin + c);
+        v.x = (v.x - mu.x) * rs.x; v.y = (v.y - mu.y) * rs.y; v.z = (v.z - mu.z) * rs.z; v.w = (v.w - mu.w) * rs.w;
+        v.x = v.x >= 0.f ? v.x : sl.x * v.x; v.y = v.y >= 0.f ? v.y : sl.y * v.y;
+        v.z = v.z >= 0.f ? v.z : sl.z * v.z; v.w = v.w >= 0.f ? v.w : sl.w * v.w;
+      }
+      *reinterpret_cast<float4*>(in_s + p * DLD + c4) = v;
+    }
+    __syncthreads();
+    const float* wc = a.w + (size_t)chunk * 25 * a.co_pad * DKC;  // this channel's row of every tap slice (uniform)
+#pragma unroll 5
+    for (int tap = 0; tap < 25; ++tap) {
+      const int dy = tap / 5, dx = tap - dy * 5;
+      const float* ap = in_s + ((py + dy) * DH + px + dx) * DLD;
+      const float* wt = wc + (size_t)tap * a.co_pad * DKC;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(ap + 4 * q);
+        acc = fmaf(v.x, wt[4 * q], acc);
+        acc = fmaf(v.y, wt[4 * q + 1], acc);
+        acc = fmaf(v.z, wt[4 * q + 2], acc);
+        acc = fmaf(v.w, wt[4 * q + 3], acc);
+      }
+    }
+  }
+  const int gy = y0 + py, gx = x0 + px;
+  if (gy < a.H && gx < a.W) a.y[((size_t)((size_t)b * a.H + gy) * a.W + gx) * a.ldy] = acc + (a.bias ? a.bias[0] : 0.f);
+}
+
 extern "C" size_t gfc_disk_conv5x5_packed_floats(int cout, int cin) {
   if (cout <= 0 || cin <= 0) return 0;
   const size_t chunks = (size_t)(cin + DKC - 1) / DKC, co_pad = (size_t)(cout + 31) / 32 * 32;
@@ -214,7 +276,7 @@ extern "C" int gfc_disk_conv5x5(const float* x, const float* mean, const float* 
   if (ntiles > 0x7FFFFFFFll) return GFC_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   // output channels in blocks of 64; a remainder of <= 32 channels goes through the one-tile variant
-  // (129 = 64 + 64 + 1: the heat-map channel costs a 32-wide block, not a 64-wide one).  Every block stays inside the
+  // (a single left-over channel -- 129 = 64 + 64 + 1, DISK's heat-map -- goes to the per-pixel VALU kernel).  Every block stays inside the
   // co_pad rows of a packed slice: co_first is a multiple of 32 and a 64-wide block is only used for > 32 channels.
   const int full = co_count / 64, rem = co_count - full * 64;
   int done = 0;
@@ -232,7 +294,8 @@ extern "C" int gfc_disk_conv5x5(const float* x, const float* mean, const float* 
     a.bias = bias ? bias + co_first + done : nullptr;
     a.y = y + done;
     a.cout = co_count - done;
-    hipLaunchKernelGGL((disk_conv5x5_kernel<1>), dim3((unsigned)ntiles, 1), dim3(256), 0, st, a);
+    if (a.cout == 1) hipLaunchKernelGGL(disk_conv5x5_c1_kernel, dim3((unsigned)ntiles), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((disk_conv5x5_kernel<1>), dim3((unsigned)ntiles, 1), dim3(256), 0, st, a);
   }
   GFC_LAUNCH_CHECK();
   return GFC_OK;
