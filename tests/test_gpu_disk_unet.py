@@ -169,3 +169,31 @@ def test_disk_module_native_network(b, h, w, k):
         assert flips <= max(2, c // 100), (flips, c)
     from parity_utils import record
     record(f"disk_module_native_{b}x{h}x{w}_k{k}", flips=flips)
+
+
+def test_config5_disk_plus_lightglue_pipeline_vs_oracle():
+    """BASELINE config 5 end to end: TwoViewPipeline(extractor = DISK on its native network, matcher = LightGlue with
+    128-d input).  The matcher's output against the CPU oracle fed with the extractor's own features (index outputs
+    bit-exact, scores within 1e-4), and the extractor's features against the CPU network + stages (checked above)."""
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+    from oracle import lightglue as olg
+
+    h, w, k = 240, 320, 512
+    g = torch.Generator().manual_seed(55)
+    img0 = torch.rand((1, 3, h, w), generator=g)
+    img1 = (img0.roll(7, -1) * 0.9 + 0.05 * torch.rand((1, 3, h, w), generator=g)).contiguous()
+    pipe = TwoViewPipeline({
+        "extractor": {"name": "extractors.disk_kornia", "weights": "synthetic", "max_num_keypoints": k},
+        "matcher": {"name": "matchers.lightglue_pretrained", "features": "disk", "weights": "synthetic",
+                    "filter_threshold": 0.1}}).eval().to(DEV)
+    size = torch.tensor([[float(w), float(h)]], device=DEV)
+    pred = pipe({"view0": {"image": img0.to(DEV), "image_size": size}, "view1": {"image": img1.to(DEV), "image_size": size}})
+    assert pred["descriptors0"].shape[-1] == 128 and pred["keypoints0"].shape[1] > k // 2
+    sd = {n[len("net."):]: v.cpu() for n, v in pipe.matcher.state_dict().items()}
+    assert sd["input_proj.weight"].shape == (256, 128)
+    ref = olg.match(sd, pred["keypoints0"].cpu(), pred["keypoints1"].cpu(), pred["descriptors0"].cpu(),
+                    pred["descriptors1"].cpu(), size.cpu(), size.cpu(), filter_threshold=0.1)
+    assert torch.equal(pred["matches0"].cpu(), ref["matches0"]) and torch.equal(pred["matches1"].cpu(), ref["matches1"])
+    assert (pred["matching_scores0"].cpu() - ref["matching_scores0"]).abs().max() < 1e-4
+    from parity_utils import record
+    record("config5_pipeline", matches=int((ref["matches0"] >= 0).sum()), keypoints=int(pred["keypoints0"].shape[1]))
