@@ -100,6 +100,49 @@ def run(n_cases=60, seed=2024):
     print("stems: worst", worst, "bad", bad)
     failures += bad
 
+    # ---- DISK's 5x5 convolution ([InstanceNorm -> PReLU ->] conv, channel-sliced output, channel sub-ranges) ----
+    bad, worst = [], 0.0
+    for case in range(max(n_cases // 2, 8)):
+        cin, cout = 4 * ri(1, 34), ri(1, 140)
+        h, w, b, gated = ri(1, 50), ri(1, 50), ri(1, 3), ri(0, 1)
+        if 480 % (cin // 4):
+            gated = 0  # the statistics kernel covers C/4 dividing 480 (every channel count of the network)
+        if gated and h * w < 2:
+            continue
+        x = torch.randn((b, cin, h, w), generator=g) * 2 + 0.3
+        wt = torch.randn((cout, cin, 5, 5), generator=g) / (5 * cin ** 0.5)
+        bias = torch.randn((cout,), generator=g) * 0.1
+        slope = torch.rand((cin,), generator=g) * 0.5
+        ref = x.double()
+        if gated:
+            ref = F.prelu(F.instance_norm(ref, eps=1e-5), slope.double())
+        ref = F.conv2d(ref, wt.double(), bias.double(), padding=2)
+        xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+        wp = torch.empty((lib.gfc_disk_conv5x5_packed_floats(cout, cin),), device=DEV)
+        wdev, bd = wt.to(DEV), bias.to(DEV)
+        nat.check(lib.gfc_disk_pack_conv5x5(nat.ptr(wdev), nat.ptr(wp), cout, cin, st), "pack5")
+        mean = rstd = sl = None
+        if gated:
+            mean, rstd, sl = torch.empty((b, cin), device=DEV), torch.empty((b, cin), device=DEV), slope.to(DEV)
+            ws = torch.empty(lib.gfc_disk_instnorm_workspace_bytes(b, cin), dtype=torch.uint8, device=DEV)
+            nat.check(lib.gfc_disk_instnorm_stats(nat.ptr(xd), b, h, w, cin, 1e-5, nat.ptr(mean), nat.ptr(rstd), nat.ptr(ws),
+                                                  ws.numel(), st), "stats")
+        first = 32 * ri(0, (cout - 1) // 32)
+        count = ri(1, cout - first)
+        pad = 4 * ri(0, 3)
+        y = torch.full((b, h, w, count + pad), float("nan"), device=DEV)
+        nat.check(lib.gfc_disk_conv5x5(nat.ptr(xd), nat.ptr(mean), nat.ptr(rstd), nat.ptr(sl), nat.ptr(wp), nat.ptr(bd),
+                                       nat.ptr(y), count + pad, b, h, w, cin, cout, first, count, st), "conv5x5")
+        torch.cuda.synchronize()
+        r = ref[:, first:first + count]
+        err = ((y[..., :count].permute(0, 3, 1, 2).double().cpu() - r).abs() / (1 + r.abs())).max().item()
+        clean = bool(torch.isnan(y[..., count:]).all())
+        worst = max(worst, err if err == err else 0.0)
+        if not (err < 3e-5 and clean):
+            bad.append(("conv5x5", cin, cout, h, w, b, gated, first, count, err, clean))
+    print("conv5x5: worst", worst, "bad", bad)
+    failures += bad
+
     bad = []
     for case in range(n_cases):
         h, w, b = ri(1, 90), ri(1, 90), ri(1, 3)
