@@ -1063,6 +1063,7 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 40 KB LDS: 4 workgroups / CU
   if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
   if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);
+  if (choice == 9) return launch_gemm_t<1, 1, 32>(g, batch, st);  // 64x32, two waves (knob only: neutral at batch 1)
   if (choice == 8) return launch_gemm_t<2, 4, 16, 2>(g, batch, st);  // 256x128: 8 accumulator tiles per wave, 2 workgroups / CU
   if (choice == 7) return launch_gemm_dma(g, batch, st);          // 128x128, LDS-DMA staging, 4 workgroups / CU  // 128x256, 61 KB LDS: 2 workgroups of 8 waves / CU
   return launch_gemm_t<2, 1, 32>(g, batch, st);

@@ -455,13 +455,14 @@ def test_linear_split_wide_dynamic_range():
 
 
 def test_gemm_tile_variants_via_knob():
-    """Every GEMM variant behind GFC_GEMM_TILE (128x256, 128x128, 64x64 with 32/16-deep K tiles, the LDS-DMA kernel)
+    """Every GEMM variant behind GFC_GEMM_TILE (128x256, 128x128, 64x64 with 32/16-deep K tiles, the LDS-DMA kernel,
+    9 = the 64x32 two-wave tile small [M, 256] problems get by default)
     passes the linear / batched tests; the knob is read once per process, hence child processes."""
     import subprocess
     import sys
 
     # 4 = gemm_nt_kernel<2,2,16>, the variant large batches (bench.py: 32 pairs) dispatch to by default
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8):
+    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9):
         env = dict(os.environ, GFC_GEMM_TILE=str(tile))
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
                             "-k", "(linear_plain or linear_concat or linear_rotary or batched_nt) and not via_knob", "-p", "no:cacheprovider"],
