@@ -110,9 +110,7 @@ SIGNATURES = {
     "gfc_conv3x3_wino": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "gfc_sp_stem_wino": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_pack_conv3x3_wino43": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "gfc_pack_conv3x3_wino43b": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gfc_sp_stem_wino43": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
-    "gfc_sp_stem_wino43b": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_disk_select_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_disk_nms_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p,

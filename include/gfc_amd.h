@@ -77,13 +77,6 @@ int gfc_pack_conv3x3_wino43(const float* w_oihw, float* w_packed, int cout, int 
 int gfc_sp_stem_wino43(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
                        const float* w2_wino43, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
                        int W, void* stream);
-/* The same stem in a second mapping (csrc/conv_wino43b.hip): all 36 transform positions of a (16 tiles x 16 output
- * channels) block in one wave (v_mfma_f32_16x16x4_f32), both transforms lane-local, no exchange epilogue.  Its filters
- * are packed by gfc_pack_conv3x3_wino43b ([cin/4][pos/4][cin%4][cout][pos%4], 36*64*64 floats). */
-int gfc_pack_conv3x3_wino43b(const float* w_oihw, float* w_packed, int cout, int cin, void* stream);
-int gfc_sp_stem_wino43b(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
-                        const float* w2_wino43b, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
-                        int W, void* stream);
 
 /* Extractor stem: conv1a (1 -> 64) + conv1b (64 -> 64) + 2x2 max-pool in ONE launch.  The first layer is
  * recomputed per workgroup on the 18x18 halo of its 16x16 tile from a 20x20 image patch in LDS, so its

@@ -304,7 +304,7 @@ def test_conv3x3_winograd(cin, cout, h, w, pool, bn):
            direct_fp32_mfma_max_abs_err=errs.get("direct", -1.0))
 
 
-@pytest.mark.parametrize("variant", ["f23", "f43", "f43b"])
+@pytest.mark.parametrize("variant", ["f23", "f43"])
 @pytest.mark.parametrize("h,w,bn,b", [(48, 64, True, 2), (37, 51, True, 2), (32, 32, False, 2), (480, 640, True, 2),
                                       (2, 2, True, 1), (16, 33, False, 3), (100, 200, True, 20)])
 def test_stem_winograd(h, w, bn, b, variant):
@@ -335,14 +335,10 @@ def test_stem_winograd(h, w, bn, b, variant):
         w2w = torch.empty((16 * 64 * 64,), device=DEV)
         nat.check(lib.gfc_pack_conv3x3_wino(nat.ptr(D(w2)), nat.ptr(w2w), 64, 64, st()), "pack_wino")
         fn = lib.gfc_sp_stem_wino
-    elif variant == "f43":
+    else:
         w2w = torch.empty((36 * 64 * 64,), device=DEV)
         nat.check(lib.gfc_pack_conv3x3_wino43(nat.ptr(D(w2)), nat.ptr(w2w), 64, 64, st()), "pack_wino43")
         fn = lib.gfc_sp_stem_wino43
-    else:
-        w2w = torch.empty((36 * 64 * 64,), device=DEV)
-        nat.check(lib.gfc_pack_conv3x3_wino43b(nat.ptr(D(w2)), nat.ptr(w2w), 64, 64, st()), "pack_wino43b")
-        fn = lib.gfc_sp_stem_wino43b
     nat.check(fn(nat.ptr(D(img.reshape(b, h, w))), nat.ptr(w1p), nat.ptr(D(b1)), nat.ptr(D(s1)), nat.ptr(D(t1)),
                  nat.ptr(w2w), nat.ptr(D(b2)), nat.ptr(D(s2)), nat.ptr(D(t2)), nat.ptr(y), b, h, w, st()), "stem")
     torch.cuda.synchronize()
