@@ -215,8 +215,6 @@ def stem_kernel_name(arg):
         return "stem_wino43_kernel (stem: conv1a on the matrix pipe + conv1b Winograd F(4x4,3x3) + ReLU + BN + 2x2 max-pool)"
     if mode == "winograd":
         return "conv3x3_wino_kernel<true, true> (stem: conv1a direct + conv1b Winograd F(2x2,3x3) + ReLU + BN + 2x2 max-pool)"
-    if mode == "split":
-        return "conv3x3_split_kernel (stem, experimental split arithmetic)"
     return "conv3x3_mfma_kernel<true, true, 16, false> (stem: conv1a + conv1b 3x3 + ReLU + BN + 2x2 max-pool)"
 
 
@@ -352,18 +350,13 @@ def main():
                          "c4 = configs[3] shape (1024x1024, 2048 kpts) for information")
     ap.add_argument("--joint-extract", type=int, default=1,
                     help="1: run the extractor once on both views' images (2*pairs images per call)")
-    ap.add_argument("--experimental", action="store_true",
-                    help="also run the frozen, opt-in `experimental_split_arithmetic` leg (bf16x3-split MFMA; information "
-                         "only, never `value`); off by default")
-    ap.add_argument("--no-experimental", action="store_true", help="accepted for older scripts; the leg is off by default")
+    ap.add_argument("--no-experimental", action="store_true",
+                    help="accepted for older scripts (the split-arithmetic leg was retired in round 4)")
     ap.add_argument("--no-batch1", action="store_true",
                     help="skip the informational `batch1` leg (single-pair latency of the batch-1 evaluation regime)")
-    ap.add_argument("--linear-arithmetic", default=None, choices=[None, "fp32", "split"],
-                    help="LightGlue GEMMs of the timed path (see --conv-arithmetic)")
-    ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "split", "winograd"],
-                    help="3x3 convolutions of the timed path: fp32 MFMA (default) or the experimental bf16x3-split MFMA "
-                         "products at fp32 accuracy; the default run additionally reports the split variant as "
-                         "`experimental_split_arithmetic` (N = 1 only)")
+    ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "winograd"],
+                    help="3x3 convolutions of the timed path: Winograd F(2x2,3x3) / F(4x4,3x3) stem on fp32 MFMA (default) "
+                         "or the direct implicit GEMM on fp32 MFMA")
     ap.add_argument("--rehearse-cpu", action="store_true",
                     help="no GPU work: exercise only the multi-process plumbing (rendezvous, barriers, max-reduce, "
                          "final gather, JSON) on gloo with a dummy step; never a measurement")
@@ -388,8 +381,7 @@ def main():
                                       "nms_radius": 3, "force_num_keypoints": True,
                                       "conv_arithmetic": args.conv_arithmetic}).eval().to(dev)
     mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
-                               "width_confidence": -1, "linear_arithmetic": args.linear_arithmetic,
-                               "attention_arithmetic": args.linear_arithmetic}).eval().to(dev)
+                               "width_confidence": -1}).eval().to(dev)
     if args.workload == "c4":
         H, W, K = 1024, 1024, 2048
         STEM_FLOPS_PER_IMAGE = 2 * 9 * (1 * 64 + 64 * 64) * H * W
@@ -457,41 +449,13 @@ def main():
     trace.close()
     atrace.close()
 
-    # information only, opt-in: the same steps with the frozen experimental split-bf16 arithmetic (never `value`)
-    split_info = None
-    if (args.experimental and world == 1 and args.conv_arithmetic is None and args.linear_arithmetic is None
-            and args.workload == "c2"):
-        try:
-            ext_s = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": K,
-                                                "detection_threshold": 0.0, "nms_radius": 3, "force_num_keypoints": True,
-                                                "conv_arithmetic": "split"}).eval().to(dev)
-            mat_s = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
-                                         "width_confidence": -1, "linear_arithmetic": "split",
-                                         "attention_arithmetic": "split"}).eval().to(dev)
-            with torch.no_grad():
-                for _ in range(args.warmup):
-                    step(ext_s, mat_s)
-                torch.cuda.synchronize(dev)
-                ts = time.perf_counter()
-                for _ in range(args.steps):
-                    _, _, pred_s = step(ext_s, mat_s)
-                torch.cuda.synchronize(dev)
-                dts = time.perf_counter() - ts
-            same = (pred_s["matches0"] >= 0).sum().item(), (pred["matches0"] >= 0).sum().item()
-            split_info = {"value": round(b * args.steps / dts, 3), "unit": "image-pairs/sec",
-                          "ms_per_step": round(dts / args.steps * 1e3, 3), "matches_split_vs_fp32": list(same),
-                          "note": "frozen experiment (--experimental): 3x3 convolutions, LightGlue GEMMs and attention "
-                                  "products as bf16x3-split MFMA products at fp32-level error; opt-in, NOT the headline"}
-        except Exception as e:  # noqa: BLE001
-            split_info = {"value": None, "error": repr(e)[:200]}
     if rank == 0:
         allrec = torch.cat(gathered)
         n_pairs_total = allrec.shape[0]
         mean_matches = float(allrec[:, 0].mean())
         value = world * b * args.steps / elapsed
         wino = conv_mode_of(args.conv_arithmetic) == "winograd"
-        default_shape = args.workload == "c2" and b == 32 and args.joint_extract and wino \
-            and args.linear_arithmetic is None
+        default_shape = args.workload == "c2" and b == 32 and args.joint_extract and wino
 
         # ---- dominant kernel: attention (SURVEY.md 8d "attention-MFMA roofline") ------------------------------
         # one product = Q.K^T or P.V of one problem over its 4 heads: 2 * K * K * 64 * 4 FLOP
@@ -509,8 +473,6 @@ def main():
             return flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
 
         att_kernel = ("attention_kernel<2, 4>" if 2 * b * 4 * ((K + 255) // 256) >= 1024 else "attention_kernel<1, 4>")
-        if args.linear_arithmetic == "split":
-            att_kernel = "attention_split_kernel (experimental split arithmetic)"
         att_traffic, att_src = pmc_traffic_bytes("attention_kernel<2, 4>") if default_shape else (None, None)
         ach = tflops(att_alg, att_ms)
         roof = {"bound": "mfma",
@@ -616,11 +578,6 @@ def main():
                 "note": "registers-only v_mfma_f32_32x32x2_f32 loop on every SIMD, measured after the timed region"}
         except Exception as e:  # noqa: BLE001
             out["roofline"]["sustained_mfma_probe"] = {"tflops": None, "error": repr(e)[:120]}
-        if split_info is not None:
-            out["experimental_split_arithmetic"] = split_info
-        if args.conv_arithmetic == "split" or args.linear_arithmetic == "split":
-            out["dtype"] = "f32 via 3 x bf16 split MFMA (experimental), f32 elsewhere"
-            out["roofline"]["note"] = "split arithmetic: not fp32-MFMA kernels; frac is fp32-equivalent FLOPs / fp32 peak"
         if args.workload == "c2" and not args.no_self_check:
             try:
                 out["self_check"] = self_check(v0, v1, p0, p1, pred)

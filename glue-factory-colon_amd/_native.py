@@ -26,7 +26,7 @@ class SpParams(Structure):
                 ("wh", c_void_p), ("bias_h", c_void_p), ("scale_h", c_void_p), ("shift_h", c_void_p),
                 ("wp", c_void_p), ("bias_p", c_void_p), ("scale_p", c_void_p), ("shift_p", c_void_p),
                 ("wd", c_void_p), ("bias_d", c_void_p), ("scale_d", c_void_p), ("shift_d", c_void_p),
-                ("desc_dim", c_int), ("conv_mode", c_int), ("w_split", c_void_p * 8), ("wh_split", c_void_p),
+                ("desc_dim", c_int), ("conv_mode", c_int),
                 ("w_wino", c_void_p * 8), ("wh_wino", c_void_p), ("w_stem_wino43", c_void_p)]
 
 
@@ -44,10 +44,7 @@ class LgParams(Structure):
                  ("posenc_wr", c_void_p), ("posenc_dim", c_int)]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in _LG_ARRAYS]
                 + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in ("final_proj_w", "final_proj_b", "matchability_w",
-                                                               "matchability_b", "token_w", "token_b")]
-                + [("linear_mode", c_int), ("attention_mode", c_int)]
-                + [(n, c_void_p * GFC_LG_MAX_LAYERS) for n in ("wqkv_split", "s_ffn0_split", "s_ffn3_split",
-                                                               "c_qkv_split", "c_ffn0_split", "c_ffn3_split")])
+                                                               "matchability_b", "token_w", "token_b")])
 
 
 _lib = None
@@ -99,19 +96,11 @@ SIGNATURES = {
     "gfc_nn_match": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_int] + [c_void_p] * 7
                      + [c_size_t, c_void_p]),
     "gfc_eval_matches_homography": (c_int, [c_void_p] * 5 + [c_int] * 3 + [c_float] * 2 + [c_void_p] * 3),
-    "gfc_pack_conv3x3_split": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
-    "gfc_conv3x3_split": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
-    "gfc_pack_linear_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
-    "gfc_linear_split": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_float, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "gfc_attention_split": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
-                                    c_int, c_int, c_float, c_void_p]),
     "gfc_pack_conv3x3_wino": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gfc_conv3x3_wino": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "gfc_sp_stem_wino": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_pack_conv3x3_wino43": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gfc_sp_stem_wino43": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
-    "gfc_sp_stem_split": (c_int, [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "gfc_disk_select_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_disk_nms_select": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_size_t, c_void_p]),

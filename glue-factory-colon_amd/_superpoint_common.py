@@ -51,13 +51,13 @@ class PackedSuperPoint:
             return None if t is None else dev(t)
 
         # 3x3 convolutions: "winograd" (default; F(2x2,3x3) on the fp32 matrix pipe, csrc/conv_wino.hip: fp32 products
-        # and accumulation, 2.25x fewer of them), "fp32" (direct implicit GEMM on fp32 MFMA, csrc/conv.hip) or the
-        # EXPERIMENTAL opt-in "split" (bf16x3-split MFMA products, csrc/conv_split.hip).  $GFC_CONV_MODE overrides the
-        # default for modules that do not set conf.conv_arithmetic.
+        # and accumulation, 2.25x fewer of them) or "fp32" (direct implicit GEMM on fp32 MFMA, csrc/conv.hip).
+        # $GFC_CONV_MODE overrides the default for modules that do not set conf.conv_arithmetic.  (The round-1
+        # "split" arithmetic -- bf16x3-split MFMA products -- was retired from the library in round 4.)
         mode = conv_mode if conv_mode is not None else os.environ.get("GFC_CONV_MODE", "winograd")
-        if mode not in ("fp32", "split", "winograd"):
-            raise ValueError(f"conv_mode {mode!r}: 'fp32', 'winograd' or 'split'")
-        self.params.conv_mode = {"fp32": 0, "split": 1, "winograd": 2}[mode]
+        if mode not in ("fp32", "winograd"):
+            raise ValueError(f"conv_mode {mode!r}: 'fp32' or 'winograd'")
+        self.params.conv_mode = {"fp32": 0, "winograd": 2}[mode]
 
         def pack_wino(w):
             """Filters transformed for Winograd F(2x2,3x3) (G g G^T in float64, done by the library) in fragment order."""
@@ -68,18 +68,8 @@ class PackedSuperPoint:
             self.keep.extend([w, out])
             return out
 
-        def pack_split(w):
-            w = w.detach().to(device=device, dtype=torch.float32).contiguous()
-            out = torch.empty((w.numel() * 3,), device=device, dtype=torch.bfloat16)
-            nat.check(lib.gfc_pack_conv3x3_split(nat.ptr(w), nat.ptr(out), w.shape[0], w.shape[1], st),
-                      "gfc_pack_conv3x3_split")
-            self.keep.append(out)
-            return out
-
         for i, (w, b, sc, sh) in enumerate(layers):
             self.params.w[i] = pack3x3(w).data_ptr()
-            if mode == "split" and i >= 1:
-                self.params.w_split[i] = pack_split(w).data_ptr()
             if mode == "winograd" and i >= 1:
                 self.params.w_wino[i] = pack_wino(w).data_ptr()
             if mode == "winograd" and i == 1 and tuple(w.shape[:2]) == (64, 64):
@@ -95,8 +85,6 @@ class PackedSuperPoint:
             self.params.shift[i] = sh.data_ptr() if sh is not None else None
         # merged 3x3 heads
         wh = pack3x3(torch.cat([head_p[0], head_d[0]], 0))
-        if mode == "split":
-            self.params.wh_split = pack_split(torch.cat([head_p[0], head_d[0]], 0)).data_ptr()
         if mode == "winograd":
             self.params.wh_wino = pack_wino(torch.cat([head_p[0], head_d[0]], 0)).data_ptr()
         bh = dev(torch.cat([head_p[1], head_d[1]], 0))

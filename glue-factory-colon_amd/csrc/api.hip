@@ -139,10 +139,7 @@ static int traced_stem(gfc_trace* tr, hipStream_t st, const gfc_sp_params* p, co
                        int W) {
   const bool rec = tr && tr->start && tr->stop && tr->count < tr->capacity;
   if (rec && hipEventRecord((hipEvent_t)tr->start[tr->count], st) != hipSuccess) return GFC_ERR_LAUNCH;
-  int s = p->conv_mode == 1
-              ? gfc_sp_stem_split(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_split[1], p->bias[1],
-                                  p->scale[1], p->shift[1], y, B, H, W, st)
-          : (p->conv_mode == 2 && p->w_stem_wino43 && gfc_knobs().stem_f43 != 0)
+  int s = (p->conv_mode == 2 && p->w_stem_wino43 && gfc_knobs().stem_f43 != 0)
               ? gfc_sp_stem_wino43(x, p->w[0], p->bias[0], p->scale[0], p->shift[0], p->w_stem_wino43, p->bias[1],
                                    p->scale[1], p->shift[1], y, B, H, W, st)
           : p->conv_mode == 2
@@ -163,16 +160,11 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   if (!p || !image || !heatmap || !desc_raw || !ws || B <= 0 || (C != 1 && C != 3) || H < 8 || W < 8)
     return GFC_ERR_INVALID;
   if (p->desc_dim <= 0) return GFC_ERR_INVALID;
-  if (p->conv_mode < 0 || p->conv_mode > 2) return GFC_ERR_INVALID;
+  if (p->conv_mode != 0 && p->conv_mode != 2) return GFC_ERR_INVALID;  // 1 (split arithmetic) was retired in round 4
   if (p->conv_mode == 2) {
     if (!p->wh_wino) return GFC_ERR_INVALID;
     for (int i = 1; i < 8; ++i)
       if (!p->w_wino[i]) return GFC_ERR_INVALID;
-  }
-  if (p->conv_mode == 1) {
-    if (!p->wh_split) return GFC_ERR_INVALID;
-    for (int i = 1; i < 8; ++i)
-      if (!p->w_split[i]) return GFC_ERR_INVALID;
   }
   if (ws_bytes < gfc_sp_workspace_bytes(B, C, H, W)) return GFC_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
@@ -190,11 +182,8 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   const int* Ws = pl.W;
   // conv1a + conv1b + pool in one launch (conv1a is recomputed on the halo tile, never written to HBM)
   GFC_TRY(traced_stem(trace, st, p, x, Bf, B, Hs[1], Ws[1]));
-  // 3x3 layers after the stem: fp32 MFMA (default) or the experimental bf16x3-split arithmetic
+  // 3x3 layers after the stem: Winograd F(2x2,3x3) (default) or the direct implicit GEMM, both on fp32 MFMA
   auto conv = [&](int li, const float* in, float* out, int hh, int ww, int ci, int co, int pool) -> int {
-    if (p->conv_mode == 1)
-      return gfc_conv3x3_split(in, p->w_split[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1,
-                               pool, st);
     if (p->conv_mode == 2)
       return gfc_conv3x3_wino(in, p->w_wino[li], p->bias[li], p->scale[li], p->shift[li], out, B, hh, ww, ci, co, 1,
                               pool, st);
@@ -210,9 +199,7 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   GFC_TRY(conv(6, Bf, A, Hs[4], Ws[4], 128, 128, 0));
   GFC_TRY(conv(7, A, Bf, Hs[4], Ws[4], 128, 128, 0));
   // merged 3x3 heads: [detector hidden | descriptor hidden]
-  if (p->conv_mode == 1)
-    GFC_TRY(gfc_conv3x3_split(Bf, p->wh_split, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
-  else if (p->conv_mode == 2)
+  if (p->conv_mode == 2)
     GFC_TRY(gfc_conv3x3_wino(Bf, p->wh_wino, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
   else
     GFC_TRY(gfc_conv3x3(Bf, p->wh, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
@@ -332,49 +319,36 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
   void* att_ws = (char*)hbuf + gfc_align((size_t)R * 512 * 4);
   // scratch is indexed [problem][head][max_n queries]: n_problems * maxn <= R for packed rows
   const size_t att_ws_bytes = ((size_t)n_problems * maxn <= (size_t)R) ? lg_attn_scratch_bytes(R) : 0;
-  // fp32 MFMA GEMM (default) or the experimental split arithmetic for the six large GEMMs of the layer
-  const bool split = p->linear_mode == 1;
-  if (split && (p->s_out_w[l] || p->c_out_w[l] || !p->wqkv_split[l] || !p->s_ffn0_split[l] || !p->s_ffn3_split[l] ||
-                !p->c_qkv_split[l] || !p->c_ffn0_split[l] || !p->c_ffn3_split[l]))
-    return GFC_ERR_INVALID;
-  // attention: fp32 MFMA (default; with its key split for small problem sets) or the experimental split arithmetic
-  const bool att_split = p->attention_mode == 1 && (long long)n_problems * 4 * ((maxn + 127) / 128) >= 512;
+  // attention on fp32 MFMA (with its key split for small problem sets)
   auto attn = [&](const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* probs) -> int {
     const bool rec = trace_begin(tr, st);
-    const int s = att_split
-                      ? gfc_attention_split(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, st)
-                      : gfc_attention(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, att_ws,
-                                      att_ws_bytes, st);
+    const int s = gfc_attention(q, ldq, k, ldk, v, ldv, ctx, D, probs, n_problems, maxn, 4, 0.125f, att_ws, att_ws_bytes, st);
     trace_end(tr, st, rec);
     return s;
   };
-  auto lin = [&](const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w, const void* wsp,
-                 int ldw, const float* bias, const float* resid, const float* rc, const float* rs, int rot_cols, float* y,
-                 int ldy, int n) -> int {
-    if (split)
-      return gfc_linear_split(a0, lda0, k0, a1, lda1, k1, wsp, bias, nullptr, nullptr, 1.f, resid, rc, rs, rot_cols, y, ldy,
-                              R, n, st);
+  auto lin = [&](const float* a0, int lda0, int k0, const float* a1, int lda1, int k1, const float* w, int ldw,
+                 const float* bias, const float* resid, const float* rc, const float* rs, int rot_cols, float* y, int ldy,
+                 int n) -> int {
     return gfc_linear(a0, lda0, k0, a1, lda1, k1, w, ldw, bias, nullptr, nullptr, 1.f, resid, rc, rs, rot_cols, y, ldy, R,
                       n, st);
   };
   // ffn[0] -> LayerNorm -> GELU (lightglue.py:143-148) into hbuf: one row-owning kernel once there are enough
   // 128-row tiles to cover the chip (>= 128: batch >= 8 pairs of 1024 points), else GEMM + in-place LayerNorm pass
-  const bool ffn_fused = !split && (gfc_knobs().ffn_fused >= 0 ? gfc_knobs().ffn_fused != 0 : R >= 128 * 128);  // knob: 0 off, 1 / 2 tile variants
-  auto ffn01 = [&](const float* a0, const float* a1, const float* w0, const void* w0_split, const float* b0,
-                   const float* ln_g, const float* ln_b) -> int {
+  const bool ffn_fused = gfc_knobs().ffn_fused >= 0 ? gfc_knobs().ffn_fused != 0 : R >= 128 * 128;  // knob: 0 off, 1 / 2 tile variants
+  auto ffn01 = [&](const float* a0, const float* a1, const float* w0, const float* b0, const float* ln_g,
+                   const float* ln_b) -> int {
     if (ffn_fused) return gfc_linear_layernorm_gelu(a0, D, D, a1, D, D, w0, 512, b0, ln_g, ln_b, hbuf, 512, R, 512, st);
-    GFC_TRY(lin(a0, D, D, a1, D, D, w0, w0_split, 512, b0, nullptr, nullptr, nullptr, 0, hbuf, 512, 512));
+    GFC_TRY(lin(a0, D, D, a1, D, D, w0, 512, b0, nullptr, nullptr, nullptr, 0, hbuf, 512, 512));
     return gfc_layernorm_gelu(hbuf, 512, R, 512, ln_g, ln_b, st);
   };
   const float* xs = x_in ? x_in : x;  // what the self block reads
   {
 
     // ---- self block (lightglue.py:151-164) ----
-    if (csb && !split)
+    if (csb)
       GFC_TRY(gfc_linear_rot_packed(xs, D, D, p->wqkv[l], D, p->bqkv[l], csb, 512, qkv, 768, R, 768, st));
     else
-      GFC_TRY(lin(xs, D, D, nullptr, 0, 0, p->wqkv[l], p->wqkv_split[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768,
-                  768));
+      GFC_TRY(lin(xs, D, D, nullptr, 0, 0, p->wqkv[l], D, p->bqkv[l], nullptr, cosb, sinb, 512, qkv, 768, 768));
     GFC_TRY(attn(qkv, 768, qkv + 256, 768, qkv + 512, 768, self_p));
     // out_proj is either a GEMM of its own, or (s_out_w == NULL) already folded into ffn0's second
     // K block at load time: [x | ctx] . [W0a | W0b.Wo]^T + (b0 + W0b.bo)
@@ -384,12 +358,10 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1s = msg;
     }
-    GFC_TRY(ffn01(xs, a1s, p->s_ffn0_w[l], p->s_ffn0_split[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l]));
-    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], p->s_ffn3_split[l], 512, p->s_ffn3_b[l], xs, nullptr, nullptr,
-                0, x, D, D));
+    GFC_TRY(ffn01(xs, a1s, p->s_ffn0_w[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l]));
+    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], xs, nullptr, nullptr, 0, x, D, D));
     // ---- cross block (lightglue.py:193-222) ----
-    GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], p->c_qkv_split[l], D, p->c_qkv_b[l], nullptr, nullptr, nullptr, 0,
-                qkv, 512, 512));
+    GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, nullptr, 0, qkv, 512, 512));
     GFC_TRY(attn(qkv, 512, qkv, 512, qkv + 256, 512, cross_p));
     const float* a1c = ctx;
     if (p->c_out_w[l]) {
@@ -397,9 +369,8 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1c = msg;
     }
-    GFC_TRY(ffn01(x, a1c, p->c_ffn0_w[l], p->c_ffn0_split[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l]));
-    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], p->c_ffn3_split[l], 512, p->c_ffn3_b[l], x, nullptr, nullptr,
-                0, x, D, D));
+    GFC_TRY(ffn01(x, a1c, p->c_ffn0_w[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l]));
+    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], x, nullptr, nullptr, 0, x, D, D));
     }
   return GFC_OK;
 }

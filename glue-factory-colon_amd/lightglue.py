@@ -91,8 +91,6 @@ class LightGlue(nn.Module):
         "name": "lightglue",
         "input_dim": 256,
         "add_scale_ori": False,
-        "linear_arithmetic": None,  # MI355X addition: None = fp32 MFMA (or $GFC_LINEAR_MODE); "split" = experimental
-        "attention_arithmetic": None,  # likewise for self / cross attention ($GFC_ATTN_MODE)
         "descriptor_dim": 256,
         "n_layers": 9,
         "num_heads": 4,
@@ -247,33 +245,6 @@ class LightGlue(nn.Module):
 
         p = nat.LgParams()
         p.n_layers, p.input_dim = conf.n_layers, conf.input_dim
-        # EXPERIMENTAL opt-in: "split" (or GFC_LINEAR_MODE=split) runs the six large GEMMs per layer as bf16x3-split
-        # MFMA products at fp32 accuracy (csrc/gemm.hip, gemm_nt_split_kernel); default: fp32 MFMA
-        mode = conf.linear_arithmetic if conf.linear_arithmetic is not None else os.environ.get("GFC_LINEAR_MODE", "fp32")
-        if mode not in ("fp32", "split"):
-            raise ValueError(f"linear_arithmetic {mode!r}: 'fp32' or 'split'")
-        if mode == "split" and not conf.fold_out_proj:
-            if conf.linear_arithmetic is not None:
-                raise ValueError("linear_arithmetic 'split' needs fold_out_proj")
-            mode = "fp32"  # requested through the environment only: modules with separate out_proj GEMMs keep fp32
-        p.linear_mode = 1 if mode == "split" else 0
-        amode = (conf.attention_arithmetic if conf.attention_arithmetic is not None
-                 else os.environ.get("GFC_ATTN_MODE", "fp32"))
-        if amode not in ("fp32", "split"):
-            raise ValueError(f"attention_arithmetic {amode!r}: 'fp32' or 'split'")
-        p.attention_mode = 1 if amode == "split" else 0
-        lib, st = nat.lib(), nat.stream_ptr(device)
-
-        def split(ptr_attr, i, w):
-            """Packed bf16x3 copy of weight `w` [N, K] for gfc_linear_split."""
-            if mode != "split":
-                return
-            w = w.detach().to(device=device, dtype=torch.float32).contiguous()
-            out = torch.empty((3 * w.numel(),), device=device, dtype=torch.bfloat16)
-            nat.check(lib.gfc_pack_linear_split(nat.ptr(w), w.shape[1], nat.ptr(out), w.shape[0], w.shape[1], st),
-                      "gfc_pack_linear_split")
-            keep.extend([w, out])
-            getattr(p, ptr_attr)[i] = out.data_ptr()
         if conf.input_dim != conf.descriptor_dim:
             p.input_proj_w, p.input_proj_b = dev(self.input_proj.weight), dev(self.input_proj.bias)
         p.posenc_wr = dev(self.posenc.Wr.weight)
@@ -299,26 +270,20 @@ class LightGlue(nn.Module):
         for i, layer in enumerate(self.transformers):
             sa, ca = layer.self_attn, layer.cross_attn
             p.wqkv[i] = dev(sa.Wqkv.weight[src])
-            split("wqkv_split", i, sa.Wqkv.weight[src])
             p.bqkv[i] = dev(sa.Wqkv.bias[src])
             if not fold:
                 p.s_out_w[i], p.s_out_b[i] = dev(sa.out_proj.weight), dev(sa.out_proj.bias)
                 p.c_out_w[i], p.c_out_b[i] = dev(ca.to_out.weight), dev(ca.to_out.bias)
             w0, b0 = ffn0(sa.ffn[0], sa.out_proj)
             p.s_ffn0_w[i], p.s_ffn0_b[i] = dev(w0), dev(b0)
-            split("s_ffn0_split", i, w0)
             p.s_ln_g[i], p.s_ln_b[i] = dev(sa.ffn[1].weight), dev(sa.ffn[1].bias)
             p.s_ffn3_w[i], p.s_ffn3_b[i] = dev(sa.ffn[3].weight), dev(sa.ffn[3].bias)
-            split("s_ffn3_split", i, sa.ffn[3].weight)
             p.c_qkv_w[i] = dev(torch.cat([ca.to_qk.weight, ca.to_v.weight], 0))
-            split("c_qkv_split", i, torch.cat([ca.to_qk.weight, ca.to_v.weight], 0))
             p.c_qkv_b[i] = dev(torch.cat([ca.to_qk.bias, ca.to_v.bias], 0))
             w0, b0 = ffn0(ca.ffn[0], ca.to_out)
             p.c_ffn0_w[i], p.c_ffn0_b[i] = dev(w0), dev(b0)
-            split("c_ffn0_split", i, w0)
             p.c_ln_g[i], p.c_ln_b[i] = dev(ca.ffn[1].weight), dev(ca.ffn[1].bias)
             p.c_ffn3_w[i], p.c_ffn3_b[i] = dev(ca.ffn[3].weight), dev(ca.ffn[3].bias)
-            split("c_ffn3_split", i, ca.ffn[3].weight)
         for i, head in enumerate(self.log_assignment):
             p.final_proj_w[i], p.final_proj_b[i] = dev(head.final_proj.weight), dev(head.final_proj.bias)
             p.matchability_w[i] = dev(head.matchability.weight.reshape(-1))

@@ -45,7 +45,7 @@ class SuperPoint(BaseModel):
         "filter_specular_keypoints": True,
         # MI355X addition, arithmetic of the 3x3 convolutions: None = $GFC_CONV_MODE or "winograd" (Winograd F(2x2,3x3)
         # on fp32 MFMA: same fp32 products / accumulation, 2.25x fewer of them); "fp32" = direct implicit GEMM on fp32
-        # MFMA; "split" = experimental bf16x3-split MFMA products (csrc/conv_split.hip)
+        # MFMA
         "conv_arithmetic": None,
     }
     required_data_keys = ["image"]

@@ -160,12 +160,9 @@ typedef struct {
   const float* scale_d;
   const float* shift_d;
   int desc_dim;
-  /* EXPERIMENTAL, opt-in: conv_mode = 1 runs the 3x3 convolutions of gfc_sp_dense (conv1b ... conv4b, merged heads)
-   * as bf16x3-split MFMA products at fp32 accuracy (gfc_conv3x3_split); w_split[1..7] / wh_split are the weights
-   * packed by gfc_pack_conv3x3_split (w_split[0] unused: conv1a stays fp32 VALU).  conv_mode = 0 (default): fp32 MFMA. */
+  /* conv_mode = 0: direct implicit GEMM on fp32 MFMA (gfc_conv3x3 / gfc_sp_stem).  (1 was the round-1 bf16x3-split
+   * arithmetic, retired from the library in round 4: gfc_sp_dense rejects it.) */
   int conv_mode;
-  const void* w_split[8];
-  const void* wh_split;
   /* conv_mode = 2: Winograd F(2x2,3x3) on the fp32 matrix pipe (gfc_conv3x3_wino / gfc_sp_stem_wino): w_wino[1..7] /
    * wh_wino are the filters transformed (in float64) and packed by gfc_pack_conv3x3_wino; w[0] (conv1a, cin = 1)
    * is still used.  Every product and accumulation is fp32; 2.25x fewer multiplications than conv_mode 0. */
@@ -354,19 +351,6 @@ typedef struct {
   /* token_confidence.{i}.token.0 (lightglue.py:69-80), i < n_layers-1 */
   const float* token_w[GFC_LG_MAX_LAYERS]; /* [256] */
   const float* token_b[GFC_LG_MAX_LAYERS]; /* [1] */
-  /* EXPERIMENTAL, opt-in: linear_mode = 1 runs the six large GEMMs of every layer (Wqkv, self ffn.0 / ffn.3, cross
-   * to_qk|to_v, cross ffn.0 / ffn.3) as bf16x3-split MFMA products at fp32 accuracy (gfc_linear_split) from weights
-   * packed by gfc_pack_linear_split; needs the folded out_proj layout (s_out_w / c_out_w NULL).  0: fp32 MFMA. */
-  int linear_mode;
-  /* EXPERIMENTAL, opt-in: attention_mode = 1 runs self / cross attention through gfc_attention_split when the problem
-   * set fills the chip (small sets keep the fp32 kernel with its key split).  0: fp32 MFMA. */
-  int attention_mode;
-  const void* wqkv_split[GFC_LG_MAX_LAYERS];
-  const void* s_ffn0_split[GFC_LG_MAX_LAYERS];
-  const void* s_ffn3_split[GFC_LG_MAX_LAYERS];
-  const void* c_qkv_split[GFC_LG_MAX_LAYERS];
-  const void* c_ffn0_split[GFC_LG_MAX_LAYERS];
-  const void* c_ffn3_split[GFC_LG_MAX_LAYERS];
 } gfc_lg_params;
 
 size_t gfc_lg_workspace_bytes(int B, int M, int N);
@@ -460,30 +444,6 @@ int gfc_nn_match(const float* desc0, const float* desc1, int B, int M, int N, in
 int gfc_eval_matches_homography(const float* kp0, const float* kp1, const int64_t* m0, const float* H,
                                 const float* Hinv, int B, int M, int N, float pos_th, float neg_th, float* out,
                                 int64_t* gt_m0_out, void* stream);
-
-/* EXPERIMENTAL, opt-in (not used by gfc_sp_dense): the 3x3 convolution on the bf16 matrix pipe at fp32 accuracy.
- * Operands are split into three bf16 planes (hi + mid + lo = 24+ mantissa bits) and each fp32 product is evaluated
- * as six bf16 MFMA products accumulated in fp32 (2.67x the fp32-MFMA peak).  gfc_pack_conv3x3_split: OIHW fp32 ->
- * [cin/16][9][cout][3][16] bf16 (cout*cin*9*3 bf16 values); gfc_conv3x3_split: same contract as gfc_conv3x3 with
- * cin % 16 == 0, cout % 64 == 0 (no cin = 1 layer). */
-int gfc_pack_conv3x3_split(const float* w_oihw, void* w_split, int cout, int cin, void* stream);
-int gfc_conv3x3_split(const float* x, const void* w_split, const float* bias, const float* scale, const float* shift,
-                      float* y, int B, int H, int W, int cin, int cout, int relu, int pool, void* stream);
-/* EXPERIMENTAL, opt-in: gfc_linear in the same split arithmetic.  gfc_pack_linear_split: W [N,K] fp32 (row stride ldw)
- * -> [N][K/16][3][16] bf16 (3*N*K values); gfc_linear_split: arguments as gfc_linear with the packed weights. */
-int gfc_pack_linear_split(const float* W, int ldw, void* w_split, int N, int K, void* stream);
-int gfc_linear_split(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const void* w_split,
-                     const float* bias, const float* scale, const float* shift, float alpha, const float* residual,
-                     const float* rot_cos, const float* rot_sin, int rot_cols, float* Y, int ldy, int M, int N,
-                     void* stream);
-/* EXPERIMENTAL, opt-in: gfc_attention in the split arithmetic (Q.K^T and P.V as six bf16 MFMA products per fp32
- * product; soft-max in fp32).  Same arguments without the key-split scratch. */
-int gfc_attention_split(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
-                        const int32_t* problems, int n_problems, int max_nq, int heads, float scale, void* stream);
-/* the stem of gfc_sp_stem with conv1b in the split arithmetic (conv1a: fp32 VALU on the halo tile, as there) */
-int gfc_sp_stem_split(const float* image, const float* w1, const float* b1, const float* s1, const float* t1,
-                      const void* w2_split, const float* b2, const float* s2, const float* t2, float* y, int B, int H,
-                      int W, void* stream);
 
 /* Soft-argmax refinement of selected key points (official variant, `refinement_radius` > 0): kpts [B,cap,2] (x, y,
  * integer valued, the first counts[b] rows of image b; counts nullable = all cap) move by the score-weighted mean

@@ -131,30 +131,6 @@ def test_superpoint_open_extreme_sizes_vs_oracle(h, w, k):
     assert p["descriptors"].shape == (1, len(ours), 256)
 
 
-def test_split_conv_arithmetic_passes_the_model_parity_tests():
-    """The experimental split arithmetic (`conv_arithmetic` / `linear_arithmetic`: bf16x3-split MFMA convolutions and
-    GEMMs) is held to the same parity tests as the fp32-MFMA path: extractor, matcher and pipeline golden vectors,
-    full-size oracle comparison.  The modes are process-wide through GFC_CONV_MODE / GFC_LINEAR_MODE, hence a child
-    process."""
-    import os
-    import subprocess
-    import sys
-
-    env = dict(os.environ, GFC_CONV_MODE="split", GFC_LINEAR_MODE="split", GFC_ATTN_MODE="split")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-p",
-                        "no:cacheprovider", "-k", "superpoint_open or superpoint_official or pipeline_golden or "
-                        "vga_1024 or specular or refinement or large_2048 or lightglue_golden or lightglue_layer0 or "
-                        "lightglue_128d or lightglue_add_scale_ori or lightglue_adaptive"],
-                       capture_output=True, text=True, env=env, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-500:])
-    # and it really is a different arithmetic: heat-maps differ in the last bits from the fp32-MFMA path
-    img = synthetic.synthetic_images(1, 96, 128, seed=8).to(DEV)
-    a = spo(max_num_keypoints=64, dense_outputs=True, conv_arithmetic="fp32")({"image": img})
-    b = spo(max_num_keypoints=64, dense_outputs=True, conv_arithmetic="split")({"image": img})
-    d = (a["dense_descriptors"] - b["dense_descriptors"]).abs().max().item()
-    assert 0 < d < 1e-5, d
-
-
 def test_direct_conv_arithmetic_passes_the_model_parity_tests():
     """The default is `conv_arithmetic: winograd` (3x3 convolutions as Winograd F(2x2,3x3) on fp32 MFMA); the direct
     implicit-GEMM convolutions (`fp32`) stay selectable and are held to the same parity tests: reference golden

@@ -211,48 +211,6 @@ def test_abi_status_codes_for_bad_arguments():
     torch.cuda.synchronize()  # nothing was launched, nothing faulted
 
 
-@pytest.mark.parametrize("cin,cout,h,w,pool", [(64, 64, 48, 64, True), (64, 128, 30, 40, False), (128, 128, 33, 47, True),
-                                               (128, 512, 15, 20, False)])
-def test_conv3x3_split_accuracy(cin, cout, h, w, pool):
-    """Experimental bf16x3-split convolution (six bf16 MFMA products per fp32 product): its error against a float64
-    reference must be of the order of the fp32-MFMA kernel's own error (both ~1e-6 here), far inside 1e-4."""
-    lib = nat.lib()
-    g = gen(cin + cout + h + 7)
-    b = 2
-    x = torch.randn((b, cin, h, w), generator=g)
-    wt = torch.randn((cout, cin, 3, 3), generator=g) / (3 * cin ** 0.5)
-    bias = torch.randn((cout,), generator=g) * 0.1
-    scale = torch.rand((cout,), generator=g) + 0.5
-    shift = torch.randn((cout,), generator=g) * 0.1
-    ref = F.relu(F.conv2d(x.double(), wt.double(), bias.double(), padding=1)) * scale.double()[None, :, None, None] \
-        + shift.double()[None, :, None, None]
-    if pool:
-        ref = F.max_pool2d(ref, 2, 2)
-    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV)
-    ho, wo = (h // 2, w // 2) if pool else (h, w)
-    outs = {}
-    for name in ("fp32", "split"):
-        y = torch.full((b, ho, wo, cout), float("nan"), device=DEV)
-        if name == "fp32":
-            wp = torch.empty((9, cout, cin), device=DEV)
-            nat.check(lib.gfc_pack_conv3x3(nat.ptr(D(wt)), nat.ptr(wp), cout, cin, st()), "pack")
-            nat.check(lib.gfc_conv3x3(nat.ptr(xd), nat.ptr(wp), nat.ptr(D(bias)), nat.ptr(D(scale)), nat.ptr(D(shift)),
-                                      nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()), "conv")
-        else:
-            ws = torch.empty((cout * cin * 9 * 3,), device=DEV, dtype=torch.bfloat16)
-            nat.check(lib.gfc_pack_conv3x3_split(nat.ptr(D(wt)), nat.ptr(ws), cout, cin, st()), "pack_split")
-            nat.check(lib.gfc_conv3x3_split(nat.ptr(xd), nat.ptr(ws), nat.ptr(D(bias)), nat.ptr(D(scale)),
-                                            nat.ptr(D(shift)), nat.ptr(y), b, h, w, cin, cout, 1, int(pool), st()),
-                      "conv_split")
-        torch.cuda.synchronize()
-        outs[name] = (y.permute(0, 3, 1, 2).double().cpu() - ref).abs().max().item()
-    assert outs["split"] < 2e-5 and outs["fp32"] < 2e-5, outs
-    assert outs["split"] < 3 * outs["fp32"] + 1e-6, outs  # same order as the fp32 matrix-pipe kernel
-    from parity_utils import record
-    record(f"conv_split_err_{cin}_{cout}_{h}x{w}_{'pool' if pool else 'nopool'}", split_max_abs_err=outs["split"],
-           fp32_mfma_max_abs_err=outs["fp32"])
-
-
 @pytest.mark.parametrize("cin,cout,h,w,pool,bn", [(64, 64, 32, 48, True, True), (64, 128, 30, 40, False, True),
                                                    (128, 128, 17, 23, True, False), (128, 512, 15, 20, False, True),
                                                    (64, 64, 33, 47, True, True), (16, 64, 5, 3, False, False),
@@ -384,74 +342,6 @@ def test_linear_plain(m, n, k):
     b = torch.randn((n,), generator=g)
     assert maxerr(run_linear(a, w, b), F.linear(a, w, b)) < 2e-5
     assert maxerr(run_linear(a, w, b, alpha=0.25), F.linear(a, w, b) / 4) < 1e-5
-
-
-def test_linear_split_accuracy():
-    """Experimental bf16x3-split GEMM: error against float64 of the order of the fp32-MFMA GEMM's, all epilogues."""
-    lib = nat.lib()
-    g = gen(77)
-    m, k0, k1, n = 777, 256, 256, 512
-    a0, a1 = torch.randn((m, k0), generator=g), torch.randn((m, k1), generator=g)
-    w = torch.randn((n, k0 + k1), generator=g) / (k0 + k1) ** 0.5
-    bias = torch.randn((n,), generator=g)
-    resid = torch.randn((m, n), generator=g)
-    cos, sin = torch.rand((m, 64), generator=g), torch.rand((m, 64), generator=g)
-    ws = torch.empty((3 * n * (k0 + k1),), device=DEV, dtype=torch.bfloat16)
-    nat.check(lib.gfc_pack_linear_split(nat.ptr(D(w)), k0 + k1, nat.ptr(ws), n, k0 + k1, st()), "pack")
-    ref = F.linear(torch.cat([a0, a1], 1).double(), w.double(), bias.double())
-
-    def run(split, residual=None, rot=False):
-        y = torch.full((m, n), float("nan"), device=DEV)
-        if residual is not None:
-            y.copy_(residual)
-        args_tail = (nat.ptr(D(bias)), None, None, 1.0, nat.ptr(y) if residual is not None else None,
-                     nat.ptr(D(cos)) if rot else None, nat.ptr(D(sin)) if rot else None, 512 if rot else 0, nat.ptr(y), n, m, n,
-                     st())
-        if split:
-            nat.check(lib.gfc_linear_split(nat.ptr(D(a0)), k0, k0, nat.ptr(D(a1)), k1, k1, nat.ptr(ws), *args_tail), "split")
-        else:
-            nat.check(lib.gfc_linear(nat.ptr(D(a0)), k0, k0, nat.ptr(D(a1)), k1, k1, nat.ptr(D(w)), k0 + k1, *args_tail),
-                      "fp32")
-        torch.cuda.synchronize()
-        return y.double().cpu()
-
-    e_split, e_fp32 = (run(True) - ref).abs().max().item(), (run(False) - ref).abs().max().item()
-    assert e_split < 1e-5 and e_split < 3 * e_fp32 + 1e-6, (e_split, e_fp32)
-    assert (run(True, residual=resid) - (ref + resid.double())).abs().max().item() < 1e-5
-    assert (run(True, rot=True) - run(False, rot=True)).abs().max().item() < 1e-5      # rotary epilogue, same code
-    from parity_utils import record
-    record("linear_split_err", split_max_abs_err=e_split, fp32_mfma_max_abs_err=e_fp32)
-
-
-def test_linear_split_wide_dynamic_range():
-    """bf16 has fp32's exponent range, so the three-plane split loses nothing on operands spanning many decades
-    (an fp16-based split would underflow): entries 10^U(-5, 3) with random signs, error measured against float64 and
-    normalised by sum_k |a_k||w_k| (the condition-aware scale of a dot product)."""
-    lib = nat.lib()
-    g = gen(2024)
-    m, k, n = 512, 512, 256
-    a = torch.randn((m, k), generator=g) * 10 ** (torch.rand((m, k), generator=g) * 8 - 5)
-    w = torch.randn((n, k), generator=g) * 10 ** (torch.rand((n, k), generator=g) * 8 - 5)
-    bias = torch.zeros((n,))
-    ref = a.double() @ w.double().T
-    scale = a.double().abs() @ w.double().abs().T
-    ws = torch.empty((3 * n * k,), device=DEV, dtype=torch.bfloat16)
-    nat.check(lib.gfc_pack_linear_split(nat.ptr(D(w)), k, nat.ptr(ws), n, k, st()), "pack")
-    errs = {}
-    for name in ("fp32", "split"):
-        y = torch.empty((m, n), device=DEV)
-        tail = (nat.ptr(D(bias)), None, None, 1.0, None, None, None, 0, nat.ptr(y), n, m, n, st())
-        if name == "split":
-            nat.check(lib.gfc_linear_split(nat.ptr(D(a)), k, k, None, 0, 0, nat.ptr(ws), *tail), "split")
-        else:
-            nat.check(lib.gfc_linear(nat.ptr(D(a)), k, k, None, 0, 0, nat.ptr(D(w)), k, *tail), "fp32")
-        torch.cuda.synchronize()
-        errs[name] = ((y.double().cpu() - ref).abs() / scale).max().item()
-    # fp32 unit round-off is 6e-8; over K = 512 terms both kernels land near 1e-6 relative to sum |a||w|
-    # (measured: fp32 MFMA 1.19e-6, split 1.00e-6) -- the split arithmetic is not the less accurate one
-    assert errs["split"] < 3e-6 and errs["split"] < 1.5 * errs["fp32"] + 6e-8, errs
-    from parity_utils import record
-    record("linear_split_wide_range_rel_err", split=errs["split"], fp32_mfma=errs["fp32"])
 
 
 def test_gemm_tile_variants_via_knob():
@@ -707,48 +597,6 @@ def test_attention(shapes, use_ws):
         assert maxerr(o[r:r + nq], ref) < 2e-5
         if nq < max(nq, nk):
             assert torch.isnan(o[r + nq:r + max(nq, nk)]).all()  # rows of other problems untouched
-
-
-def test_attention_split_accuracy():
-    """Experimental split-arithmetic attention against a float64 soft-max attention: error of the order of the
-    fp32-MFMA kernel's; ragged problems (tails, different n_q / n_kv) included."""
-    lib = nat.lib()
-    g = gen(123)
-    sizes = [(200, 333), (333, 200), (128, 64), (70, 1000)]
-    rows = sum(max(a, b) for a, b in sizes) * 2
-    qkv = torch.randn((rows, 768), generator=g)
-    qkv[:, :512] *= 1.7
-    probs, r = [], 0
-    for nq, nk in sizes:
-        probs.append([r, nq, r + nq, nk])
-        r += nq + nk
-    pt = torch.tensor(probs, dtype=torch.int32)
-    heads, scale = 4, 0.125
-    ref = torch.zeros((rows, 256), dtype=torch.float64)
-    for q0, nq, k0, nk in probs:
-        for hh in range(heads):
-            qq = qkv[q0:q0 + nq, 64 * hh:64 * hh + 64].double()
-            kk = qkv[k0:k0 + nk, 256 + 64 * hh:256 + 64 * hh + 64].double()
-            vv = qkv[k0:k0 + nk, 512 + 64 * hh:512 + 64 * hh + 64].double()
-            ref[q0:q0 + nq, 64 * hh:64 * hh + 64] = torch.softmax(qq @ kk.T * scale, -1) @ vv
-    qd = D(qkv)
-    errs = {}
-    for name in ("fp32", "split"):
-        o = torch.zeros((rows, 256), device=DEV)
-        args = (nat.ptr(qd), 768, nat.c_void_p(qd.data_ptr() + 256 * 4), 768, nat.c_void_p(qd.data_ptr() + 512 * 4), 768,
-                nat.ptr(o), 256, nat.ptr(D(pt)), len(probs), max(a for a, _ in sizes), heads, scale)
-        if name == "fp32":
-            nat.check(lib.gfc_attention(*args, None, 0, st()), "attention")
-        else:
-            nat.check(lib.gfc_attention_split(*args, st()), "attention_split")
-        torch.cuda.synchronize()
-        e = 0.0
-        for q0, nq, _, _ in probs:
-            e = max(e, (o[q0:q0 + nq].double().cpu() - ref[q0:q0 + nq]).abs().max().item())
-        errs[name] = e
-    assert errs["split"] < 1e-5 and errs["split"] < 3 * errs["fp32"] + 1e-6, errs
-    from parity_utils import record
-    record("attention_split_err", split_max_abs_err=errs["split"], fp32_mfma_max_abs_err=errs["fp32"])
 
 
 def test_attention_peaky_rows():

@@ -87,53 +87,6 @@ def bench_ffn_fused():
     report("ffn0+LN+GELU fused (rows512 kernel)", timeit(one), 2.0 * R * 512 * 512)
 
 
-def bench_attn_split():
-    lib = nat.lib()
-    st = nat.stream_ptr(DEV)
-    B, K = 32, 1024
-    R = 2 * B * K
-    qkv = torch.randn((R, 768), device=DEV)
-    o = torch.empty((R, 256), device=DEV)
-    self_p = torch.tensor([[i * K, K, i * K, K] for i in range(2 * B)], dtype=torch.int32, device=DEV)
-    cross_p = torch.tensor([[i * K, K, (B + i) * K, K] for i in range(B)]
-                           + [[(B + i) * K, K, i * K, K] for i in range(B)], dtype=torch.int32, device=DEV)
-    for name, pt in (("split self attention 64 x (1024x1024), 4 heads", self_p), ("split cross attention (2 directions)", cross_p)):
-        def fn():
-            nat.check(lib.gfc_attention_split(nat.ptr(qkv), 768, nat.c_void_p(qkv.data_ptr() + 256 * 4), 768,
-                                              nat.c_void_p(qkv.data_ptr() + 512 * 4), 768, nat.ptr(o), 256, nat.ptr(pt),
-                                              2 * B, K, 4, 0.125, st), "attention_split")
-        report(name, timeit(fn), 4.0 * 2 * B * 4 * K * K * 64)
-
-
-def bench_gemm_split():
-    """Experimental bf16x3-split GEMM at the LightGlue shapes (TFLOP/s of fp32-equivalent work)."""
-    lib = nat.lib()
-    st = nat.stream_ptr(DEV)
-    R = 65536
-    x = torch.randn((R, 256), device=DEV)
-    msg = torch.randn((R, 256), device=DEV)
-    hbuf = torch.randn((R, 512), device=DEV)
-    cos, sin = torch.rand((R, 64), device=DEV), torch.rand((R, 64), device=DEV)
-    for name, a0, a1, n, k0, k1, rot, res in [("split qkv  N=768 K=256 rotary", x, None, 768, 256, 0, True, False),
-                                              ("split qkv' N=512 K=256", x, None, 512, 256, 0, False, False),
-                                              ("split ffn0 N=512 K=256+256 (concat)", x, msg, 512, 256, 256, False, False),
-                                              ("split ffn3 N=256 K=512 residual", hbuf, None, 256, 512, 0, False, True)]:
-        w = torch.randn((n, k0 + k1), device=DEV) / 16
-        ws = torch.empty((3 * n * (k0 + k1),), device=DEV, dtype=torch.bfloat16)
-        nat.check(lib.gfc_pack_linear_split(nat.ptr(w), k0 + k1, nat.ptr(ws), n, k0 + k1, st), "pack")
-        b = torch.randn((n,), device=DEV)
-        y = torch.empty((R, n), device=DEV)
-        resid = torch.randn((R, n), device=DEV) if res else None
-
-        def fn():
-            nat.check(lib.gfc_linear_split(nat.ptr(a0), a0.shape[1], k0, nat.ptr(a1), 0 if a1 is None else a1.shape[1], k1,
-                                           nat.ptr(ws), nat.ptr(b), None, None, 1.0, nat.ptr(resid),
-                                           nat.ptr(cos) if rot else None, nat.ptr(sin) if rot else None, 512 if rot else 0,
-                                           nat.ptr(y), n, R, n, st), "linear_split")
-
-        report(name, timeit(fn), 2.0 * R * n * (k0 + k1))
-
-
 def bench_gemm_sweep():
     """Fixed vs per-K cost: N = 256, K = 256..2048 (synthetic shapes)."""
     lib = nat.lib()
@@ -260,31 +213,6 @@ def bench_conv_wino():
     report("wino stem conv1a+conv1b+pool @480x640 x64", timeit(fn2, iters=10), 2.0 * 9 * B * h * w * (64 + 64 * 64))
 
 
-def bench_conv_split():
-    """Experimental bf16x3-split convolution at the same shapes as bench_conv (TFLOP/s of fp32-equivalent work)."""
-    lib = nat.lib()
-    st = nat.stream_ptr(DEV)
-    B = 32
-    for name, h, w, cin, cout, pool in [("split conv1b 64->64 @480x640 +pool", 480, 640, 64, 64, 1),
-                                        ("split conv2a 64->64 @240x320", 240, 320, 64, 64, 0),
-                                        ("split conv3b 128->128 @120x160 +pool", 120, 160, 128, 128, 1),
-                                        ("split heads 128->512 @60x80", 60, 80, 128, 512, 0)]:
-        x = torch.randn((B, h, w, cin), device=DEV)
-        wt = torch.randn((cout, cin, 3, 3), device=DEV) / (3 * cin ** 0.5)
-        ws = torch.empty((cout * cin * 9 * 3,), device=DEV, dtype=torch.bfloat16)
-        nat.check(lib.gfc_pack_conv3x3_split(nat.ptr(wt), nat.ptr(ws), cout, cin, st), "pack")
-        bias = torch.randn((cout,), device=DEV)
-        sc = torch.rand((cout,), device=DEV) + 0.5
-        sh = torch.randn((cout,), device=DEV)
-        y = torch.empty((B, h // 2 if pool else h, w // 2 if pool else w, cout), device=DEV)
-
-        def fn():
-            nat.check(lib.gfc_conv3x3_split(nat.ptr(x), nat.ptr(ws), nat.ptr(bias), nat.ptr(sc), nat.ptr(sh), nat.ptr(y),
-                                            B, h, w, cin, cout, 1, pool, st), "conv_split")
-
-        report(name, timeit(fn, iters=10), 2.0 * 9 * B * h * w * cin * cout)
-
-
 def bench_stem():
     """The dominant kernel: conv1a + conv1b + pool in one launch (gfc_sp_stem), 64 VGA images as in bench.py."""
     lib = nat.lib()
@@ -343,10 +271,6 @@ if __name__ == "__main__":
         bench_gemm_msweep()
     if args.only == "small":
         bench_gemm_small()
-    if args.only in ("", "split"):
-        bench_conv_split()
-        bench_gemm_split()
-        bench_attn_split()
     if args.only in ("", "conv", "stem"):
         bench_stem()
     if args.only in ("", "conv"):
