@@ -186,6 +186,65 @@ def batch1_latency(dev, n_pairs: int = 24, warmup: int = 4):
 
 
 
+def c3_regime(dev, n_pairs: int = 64):
+    """Information only (never `value`): BASELINE config 3's regime -- the HPatches evaluation loop
+    (utils/export_predictions.py:36-85: batch 1 because the IMAGES differ in size; official SuperPoint + LightGlue,
+    1024 key points, detection threshold 0) on an HPatches-shaped list of mixed image shapes, through this package's
+    export loop without the file write: forward, key filtering, un-scaling, host copy of every record.  Sequential
+    loop, `workers` (pairs in flight on several streams) and `pair_batch` (N consecutive pairs: the extractor once per
+    distinct image shape, the matcher once over all N pairs with their own key-point counts)."""
+    from glue_factory_colon_amd import export_predictions as ep
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+    items = synthetic.hpatches_shaped_pairs(n_pairs, device=dev)
+    keys = ["keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1"]
+    optional = ["keypoint_scores0", "keypoint_scores1"]
+
+    def pipeline(profiled):
+        return TwoViewPipeline({
+            "extractor": {"name": "gluefactory_nonfree.superpoint", "weights": "synthetic", "max_num_keypoints": K,
+                          "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue_pretrained", "features": "superpoint", "weights": "synthetic",
+                        "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1},
+            "profile_calls": profiled}).eval().to(dev)
+
+    def run(pipe, workers, pair_batch):
+        out = []
+        ep._export_loop(enumerate(items), pipe, "cuda", keys, optional, None, False, workers, out, pair_batch)
+        return out
+
+    res = {}
+    matches = None
+    pipe = pipeline(False)
+    with torch.no_grad():
+        for tag, profiled, workers, pb in (("sequential_reference_syncs", True, 1, 1), ("sequential", False, 1, 1),
+                                           ("workers4", False, 4, 1), ("pair_batch16", False, 1, 16),
+                                           ("pair_batch32", False, 1, 32), ("pair_batch16_workers2", False, 2, 16),
+                                           ("pair_batch32_workers2", False, 2, 32)):
+            p = pipeline(True) if profiled else pipe
+            run(p, workers, pb)  # untimed: allocator and per-shape workspaces warm
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                out = run(p, workers, pb)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            res[tag] = round(n_pairs / best, 1)
+            n_m = sum(int((rec["matches0"] >= 0).sum()) for _, _, rec in out)
+            matches = n_m if matches is None else matches
+            res.setdefault("same_match_count", True)
+            res["same_match_count"] = bool(res["same_match_count"] and n_m == matches)
+    shapes = sorted({tuple(it[v]["image"].shape[-2:]) for it in items for v in ("view0", "view1")})
+    return {"unit": "image-pairs/sec", **res, "matches_total": matches,
+            "sample": f"{n_pairs} HPatches-shaped RGB pairs, image shapes {shapes} in changing combinations, official "
+                      "SuperPoint + LightGlue (superpoint+lightglue-official configuration), 1024 key points; the whole "
+                      "export loop per pair except the file write; best of two passes after one untimed pass; "
+                      "`sequential_reference_syncs` keeps the reference's per-call device synchronisations "
+                      "(two_view_pipeline.py:78-102), the other legs run with profile_calls: false"}
+
+
 def host_barrier_group(world):
     """A gloo group for the job's closing barrier (rank 0 spends about a minute on the CPU baseline after the timed region:
     the other ranks wait on the host instead of spinning in an RCCL kernel).  One node only (the bench contract), so the
@@ -588,6 +647,11 @@ def main():
                 out["batch1"] = batch1_latency(dev)
             except Exception as e:  # noqa: BLE001
                 out["batch1"] = {"pairs_per_s": None, "error": repr(e)[:200]}
+        if args.workload == "c2" and not args.no_batch1 and world == 1:
+            try:  # information only: config 3's regime at the batched rate (never `value`)
+                out["c3_regime"] = c3_regime(dev)
+            except Exception as e:  # noqa: BLE001
+                out["c3_regime"] = {"pair_batch32": None, "error": repr(e)[:200]}
         if not args.no_cpu_baseline:
             # rank 0 only, after the timed region and the gather; at N > 1 the other ranks wait at the closing barrier
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)

@@ -13,6 +13,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # GFC_AMD_LIB: another build of the same library (same-box A/B of kernel variants: tools/ab_build.sh)
 LIB_PATH = os.environ.get("GFC_AMD_LIB") or os.path.join(_PKG, "libgfc_amd.so")
 GFC_LG_MAX_LAYERS = 16
+GFC_LG_MAX_RAGGED_PAIRS = 128
 
 STATUS = {0: "GFC_OK", 1: "GFC_ERR_INVALID", 2: "GFC_ERR_WORKSPACE", 3: "GFC_ERR_UNSUPPORTED", 4: "GFC_ERR_LAUNCH"}
 
@@ -131,6 +132,10 @@ SIGNATURES = {
                               + [c_size_t, POINTER(Trace), c_void_p]),
     "gfc_lg_forward": (c_int, [POINTER(LgParams)] + [c_void_p] * 8 + [c_int] * 3 + [c_float] + [c_void_p] * 8
                        + [c_size_t, c_void_p]),
+    "gfc_lg_ragged_workspace_bytes": (c_size_t, [c_int, POINTER(c_int32), POINTER(c_int32)]),
+    "gfc_lg_forward_ragged": (c_int, [POINTER(LgParams)] + [c_void_p] * 5 + [c_int, POINTER(c_int32), POINTER(c_int32),
+                                                                            c_float] + [c_void_p] * 7
+                              + [c_size_t, POINTER(Trace), c_void_p]),
 }
 
 

@@ -13,6 +13,10 @@ from . import _native as nat
 SAMPLE_OPEN, SAMPLE_LEGACY, SAMPLE_FIXED = 0, 1, 2
 
 
+class RaggedCounts(RuntimeError):
+    """The images of one batched call kept different numbers of key points (no force_num_keypoints)."""
+
+
 def fold_bn(weight, bias, mean, var, eps=1e-3):
     """Eval-mode BatchNorm as y = x*alpha + beta, with the same fp32 operation order as
     torch's CPU kernel (invstd = 1/sqrt(var+eps); alpha = invstd*weight; beta = bias - mean*alpha)."""
@@ -250,6 +254,37 @@ def joint_pair_data(data0, data1):
     return joint
 
 
+def extract_views(model, views):
+    """`[model(v) for v in views]` (each `v` a single-image extractor input) with ONE extractor call per distinct
+    image shape among them: the views are grouped by what must agree inside a call (image shape / dtype / device, which
+    side inputs are present and their shapes), each group runs as one batch with per-image key-point counts
+    (`per_image=True`), and the predictions come back in the order given.  MI355X addition for the pair-batched
+    evaluation loop (export_predictions(pair_batch=N)): at batch 1 the layers behind the stem fill a fraction of the
+    chip.  Every image's result is what its own call returns (images of a batch are independent)."""
+    groups = {}
+    for i, v in enumerate(views):
+        for key in model.required_data_keys:
+            assert key in v, f"Missing key {key} in data"
+        im = v["image"]
+        sig = (tuple(im.shape[1:]), im.dtype, str(im.device), im.shape[0] == 1,
+               tuple((k, tuple(v[k].shape[1:])) for k in ("image_size", "specular_mask") if k in v))
+        groups.setdefault(sig, []).append(i)
+    out = [None] * len(views)
+    for sig, idx in groups.items():
+        if not sig[3] or len(idx) == 1:  # batched views (or a shape of its own): the ordinary call
+            for i in idx:
+                out[i] = model(views[i])
+            continue
+        dev = views[idx[0]]["image"].device
+        joint = {"image": torch.cat([views[i]["image"] for i in idx], 0)}
+        for key in ("image_size", "specular_mask"):
+            if key in views[idx[0]]:
+                joint[key] = torch.cat([views[i][key].to(dev) for i in idx], 0)
+        for i, pred in zip(idx, model._forward(joint, per_image=True)):
+            out[i] = pred
+    return out
+
+
 def specular_mask_bytes(data, b, device):
     """`data["specular_mask"]` ([B,1,H,W] / [B,H,W], any dtype, non-zero = keep; extractors/utils.py:16-20) as
     contiguous bytes [B,Hm,Wm] on the device, and image_size as int32 [B,2] (w, h) or None."""
@@ -311,14 +346,20 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
         n = counts.tolist()  # host sync, as torch.where in the reference
         if len(set(n)) != 1 and not per_image:
             # the reference cannot stack ragged key-point lists either (torch.stack raises)
-            raise RuntimeError(f"images of one batch yield different numbers of keypoints {n}: "
+            raise RaggedCounts(f"images of one batch yield different numbers of keypoints {n}: "
                                "use force_num_keypoints=True or batch size 1")
         if len(set(n)) == 1:
             if n[0] != kpts.shape[1]:
                 kpts, ksc = kpts[:, : n[0]].contiguous(), ksc[:, : n[0]].contiguous()
             counts_arg = None
         else:
-            counts_arg = counts  # ragged (per_image): the sampler zero-fills the slots beyond each image's count
+            # ragged (per_image): the sampler zero-fills the slots beyond each image's count.  Trimmed to the largest
+            # count first: with max_num_keypoints None the selection has H*W slots per image, and a [b, H*W, 256]
+            # descriptor tensor (630 MB per VGA pair) would be allocated, zero-filled and kept alive by the views
+            nmax = max(n)
+            if nmax != kpts.shape[1]:
+                kpts, ksc = kpts[:, :nmax].contiguous(), ksc[:, :nmax].contiguous()
+            counts_arg = counts
     if kpts.shape[1] > 0:
         desc, kout = runner.sample(desc_raw, kpts, counts_arg, sample_mode)
     else:

@@ -317,8 +317,9 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
   float* msg = (float*)((char*)ctx + gfc_align((size_t)R * 256 * 4));
   float* hbuf = (float*)((char*)msg + gfc_align((size_t)R * 256 * 4));
   void* att_ws = (char*)hbuf + gfc_align((size_t)R * 512 * 4);
-  // scratch is indexed [problem][head][max_n queries]: n_problems * maxn <= R for packed rows
-  const size_t att_ws_bytes = ((size_t)n_problems * maxn <= (size_t)R) ? lg_attn_scratch_bytes(R) : 0;
+  // scratch is indexed [problem][head][max_n queries][split]: with n_problems * maxn <= R (uniform packed rows) it holds
+  // the full 8-way key split; for ragged problem sets gfc_attention lowers the split until it fits
+  const size_t att_ws_bytes = lg_attn_scratch_bytes(R);
   // attention on fp32 MFMA (with its key split for small problem sets)
   auto attn = [&](const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, const int32_t* probs) -> int {
     const bool rec = trace_begin(tr, st);
@@ -496,6 +497,140 @@ extern "C" int gfc_lg_forward_packed(const gfc_lg_params* p, const float* kpts, 
   const LgPlan pl = lg_plan(B, M, N, true);
   return lg_forward_core(p, kpts, scale_ori, desc, size0, size1, B, M, N, threshold, m0, m1, ms0, ms1, log_assignment,
                          rows, (char*)ws, pl, attention_trace, (hipStream_t)stream);
+}
+
+// ---- ragged batch: B pairs with their own (m, n) ----
+struct LgRaggedTab {
+  int r0[GFC_LG_MAX_RAGGED_PAIRS], r1[GFC_LG_MAX_RAGGED_PAIRS], m[GFC_LG_MAX_RAGGED_PAIRS], n[GFC_LG_MAX_RAGGED_PAIRS];
+};
+struct LgRaggedPlan {
+  LgRaggedTab tab;
+  int groups, g_first[GFC_LG_MAX_RAGGED_PAIRS], g_count[GFC_LG_MAX_RAGGED_PAIRS];
+  long long R, sum_m, sum_n;
+  int maxn;
+  size_t stage;
+  LgPlan pl;
+};
+
+// rows of a group: side 0 of its pairs, then side 1 (the layout of gfc_lg_forward_packed per group)
+static bool lg_ragged_plan(int B, const int32_t* m, const int32_t* n, LgRaggedPlan& rp) {
+  if (B <= 0 || B > GFC_LG_MAX_RAGGED_PAIRS || !m || !n) return false;
+  rp.groups = 0; rp.R = 0; rp.sum_m = 0; rp.sum_n = 0; rp.maxn = 0;
+  size_t asg = 0;
+  for (int i = 0; i < B;) {
+    if (m[i] <= 0 || n[i] <= 0) return false;
+    int j = i;
+    while (j < B && m[j] == m[i] && n[j] == n[i]) ++j;
+    const int cnt = j - i;
+    rp.g_first[rp.groups] = i; rp.g_count[rp.groups] = cnt; ++rp.groups;
+    for (int k = i; k < j; ++k) {
+      rp.tab.m[k] = m[i]; rp.tab.n[k] = n[i];
+      rp.tab.r0[k] = (int)(rp.R + (long long)(k - i) * m[i]);
+      rp.tab.r1[k] = (int)(rp.R + (long long)cnt * m[i] + (long long)(k - i) * n[i]);
+    }
+    rp.R += (long long)cnt * (m[i] + n[i]);
+    rp.sum_m += (long long)cnt * m[i]; rp.sum_n += (long long)cnt * n[i];
+    if (m[i] > rp.maxn) rp.maxn = m[i];
+    if (n[i] > rp.maxn) rp.maxn = n[i];
+    const size_t a = gfc_lg_assign_workspace_bytes(cnt, m[i], n[i]);
+    if (a > asg) asg = a;
+    i = j;
+  }
+  if (rp.R > 0x7fffffffLL / 768) return false;  // row offsets x 768 columns stay inside int arithmetic of the kernels
+  for (int k = B; k < GFC_LG_MAX_RAGGED_PAIRS; ++k) rp.tab.m[k] = rp.tab.n[k] = rp.tab.r0[k] = rp.tab.r1[k] = 0;
+  // workspace: the packed plan's slots with R rows, B pairs, and the stage scratch large enough for every group's head
+  LgPlan& pl = rp.pl;
+  pl.R = (size_t)rp.R;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += gfc_align(bytes); return o; };
+  pl.x = 0; pl.msg = 0;
+  size_t stage = gfc_lg_layer_workspace_bytes((int)rp.R);
+  if (asg > stage) stage = asg;
+  rp.stage = stage;
+  pl.qkv = take(stage);
+  pl.cosb = take(pl.R * 64 * 4);
+  pl.sinb = take(pl.R * 64 * 4);
+  pl.csb = take(pl.R * 64 * 4);
+  pl.tables = take((size_t)B * (2 * 4 * 2 + 2 + 2 + 4) * 4 + 256);
+  pl.total = off;
+  return true;
+}
+
+extern "C" size_t gfc_lg_ragged_workspace_bytes(int B, const int32_t* m, const int32_t* n) {
+  LgRaggedPlan rp;
+  return lg_ragged_plan(B, m, n, rp) ? rp.pl.total : 0;
+}
+
+// the tables of lg_tables_kernel for per-pair counts (same slots: problem b = side 0 of pair b, B + b = side 1)
+__global__ void lg_ragged_tables_kernel(LgRaggedTab t, int B, const float* size0, const float* size1, int* self_p,
+                                        int* cross_p, int* row0, int* nrow, float* sizes) {
+  int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int r0 = t.r0[b], r1 = t.r1[b], M = t.m[b], N = t.n[b];
+  int* s = self_p + 4 * b;
+  s[0] = r0; s[1] = M; s[2] = r0; s[3] = M;
+  s = self_p + 4 * (B + b);
+  s[0] = r1; s[1] = N; s[2] = r1; s[3] = N;
+  int* c = cross_p + 4 * b;
+  c[0] = r0; c[1] = M; c[2] = r1; c[3] = N;
+  c = cross_p + 4 * (B + b);
+  c[0] = r1; c[1] = N; c[2] = r0; c[3] = M;
+  row0[b] = r0; nrow[b] = M;
+  row0[B + b] = r1; nrow[B + b] = N;
+  sizes[2 * b] = size0[2 * b]; sizes[2 * b + 1] = size0[2 * b + 1];
+  sizes[2 * (B + b)] = size1[2 * b]; sizes[2 * (B + b) + 1] = size1[2 * b + 1];
+}
+
+extern "C" int gfc_lg_forward_ragged(const gfc_lg_params* p, const float* kpts, const float* desc, const float* size0,
+                                     const float* size1, const float* scale_ori, int B, const int32_t* m,
+                                     const int32_t* n, float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1,
+                                     float* log_assignment, float* rows, void* ws, size_t ws_bytes,
+                                     gfc_trace* attention_trace, void* stream) {
+  if (!p || !kpts || !desc || !size0 || !size1 || !m0 || !m1 || !ms0 || !ms1 || !log_assignment || !rows || !ws)
+    return GFC_ERR_INVALID;
+  LgRaggedPlan rp;
+  if (!lg_ragged_plan(B, m, n, rp)) return GFC_ERR_INVALID;
+  if (!lg_forward_args_ok(p, B, rp.maxn, rp.maxn, scale_ori != nullptr)) return GFC_ERR_INVALID;
+  if (rows == desc) return GFC_ERR_INVALID;  // the caller's descriptors are read-only
+  if (ws_bytes < rp.pl.total) return GFC_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const LgPlan& pl = rp.pl;
+  char* base = (char*)ws;
+  float* cosb = (float*)(base + pl.cosb);
+  float* sinb = (float*)(base + pl.sinb);
+  float* csb = (float*)(base + pl.csb);
+  int* self_p = (int*)(base + pl.tables);
+  int* cross_p = self_p + 8 * B;
+  int* row0 = cross_p + 8 * B;
+  int* nrow = row0 + 2 * B;
+  float* sizes = (float*)(nrow + 2 * B);
+  const int R = (int)pl.R, D = 256;
+  const int pdim = p->posenc_dim == 0 ? 2 : p->posenc_dim;
+  hipLaunchKernelGGL(lg_ragged_tables_kernel, dim3((B + 63) / 64), dim3(64), 0, st, rp.tab, B, size0, size1, self_p,
+                     cross_p, row0, nrow, sizes);
+  GFC_LAUNCH_CHECK();
+  GFC_TRY(gfc_lg_posenc_packed(kpts, scale_ori, sizes, row0, nrow, 2 * B, rp.maxn, p->posenc_wr, pdim, cosb, sinb, csb, st));
+  const float* x_in = desc;
+  if (p->input_dim != D) {
+    const int Din = p->input_dim;
+    GFC_TRY(gfc_linear(desc, Din, Din, nullptr, 0, 0, p->input_proj_w, Din, p->input_proj_b, nullptr, nullptr, 1.f,
+                       nullptr, nullptr, nullptr, 0, rows, D, R, D, st));
+    x_in = nullptr;
+  }
+  for (int l = 0; l < p->n_layers; ++l)
+    GFC_TRY(lg_layer_impl(p, l, rows, cosb, sinb, csb, R, self_p, cross_p, 2 * B, rp.maxn, base + pl.qkv,
+                          gfc_lg_layer_workspace_bytes(R), st, l == 0 ? x_in : nullptr, attention_trace));
+  // assignment + filter, one batched call per group of equal-shape pairs (outputs are flat in pair order)
+  size_t o0 = 0, o1 = 0, os = 0;
+  for (int g = 0; g < rp.groups; ++g) {
+    const int i = rp.g_first[g], cnt = rp.g_count[g], M = rp.tab.m[i], N = rp.tab.n[i];
+    const float* x0 = rows + (size_t)rp.tab.r0[i] * D;
+    const float* x1 = rows + (size_t)rp.tab.r1[i] * D;
+    GFC_TRY(gfc_lg_assign(p, p->n_layers - 1, x0, x1, cnt, M, N, threshold, m0 + o0, m1 + o1, ms0 + o0, ms1 + o1,
+                          log_assignment + os, base + pl.qkv, rp.stage, st));
+    o0 += (size_t)cnt * M; o1 += (size_t)cnt * N; os += (size_t)cnt * (M + 1) * (N + 1);
+  }
+  return GFC_OK;
 }
 
 extern "C" int gfc_lg_forward(const gfc_lg_params* p, const float* kpts0, const float* kpts1, const float* desc0,

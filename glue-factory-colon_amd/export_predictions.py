@@ -7,11 +7,15 @@ HDF5 groups through h5py; an `.h5` output here is the same HDF5 layout, written 
 otherwise through the HDF5 C library itself (`_hdf5.py`, ctypes); other suffixes give one `.npz` archive with keys
 `"<name>/<key>"` (`load_predictions` reads both).
 
-MI355X addition (`workers` > 1): the evaluation loop runs at batch 1 (image sizes differ), whose kernels fill only
-part of the chip (conv4 at 60x80: 40 workgroups for 256 CUs).  `workers` host threads, each with its own HIP stream
-and its own replica of the model (own workspaces; the weights are read-only), process different pairs at the same
-time: 277 -> 469 pairs/s with 4 workers on VGA pairs (tools/micro/multistream_probe.py).  Records are the same and
-are written in loader order.
+MI355X additions.  The evaluation loop runs at batch 1 because the IMAGES of an HPatches-style list differ in size
+(datasets/hpatches.py:60), and batch-1 kernels fill only part of the chip (conv4 at 60x80: 40 workgroups for 256 CUs).
+* `pair_batch` = N > 1: N consecutive loader items are processed together (`model.forward_pairs`): the extractor once
+  per distinct image shape among their 2N views, the matcher ONCE over all N pairs with their own key-point counts
+  (LightGlue is image-size independent once the key points exist; gfc_lg_forward_ragged).  Records are those of the
+  sequential loop (integers identical, floats within the batch-size dependence of the kernels' summation order) and
+  are written in loader order.
+* `workers` > 1: that many host threads, each with its own HIP stream and its own replica of the model (own
+  workspaces; the weights are read-only), process different pairs -- or different pair batches -- at the same time.
 """
 import copy
 import queue
@@ -44,7 +48,32 @@ def _replicate(model):
 
 def _process(model, data, keys, optional_keys, callback_fn, as_half):
     """One pair: forward, key filtering, un-scaling, host copy (export_predictions.py:36-85)."""
-    pred = model(data)
+    return _record(model(data), data, keys, optional_keys, callback_fn, as_half)
+
+
+def _process_batch(model, datas, keys, optional_keys, callback_fn, as_half):
+    """`pair_batch` consecutive pairs through one `forward_pairs` call; one record per pair."""
+    preds = model.forward_pairs(datas) if hasattr(model, "forward_pairs") else [model(d) for d in datas]
+    preds = [_record(p, d, keys, optional_keys, callback_fn, as_half, to_host=False) for p, d in zip(preds, datas)]
+    # ONE device-to-host copy per dtype for the whole batch instead of one synchronising copy per pair and key
+    by_dtype = {}
+    for i, p in enumerate(preds):
+        for k, v in p.items():
+            by_dtype.setdefault(v.dtype, []).append((i, k, v[0]))
+    recs = [dict() for _ in preds]
+    for entries in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for _, _, t in entries]).cpu().numpy()
+        off = 0
+        for i, k, t in entries:
+            recs[i][k] = flat[off:off + t.numel()].reshape(tuple(t.shape)).copy()
+            off += t.numel()
+    recs = [{k: r[k] for k in p} for p, r in zip(preds, recs)]  # key order of the prediction
+    if as_half:
+        recs = [{k: (v.astype(np.float16) if v.dtype == np.float32 else v) for k, v in r.items()} for r in recs]
+    return recs
+
+
+def _record(pred, data, keys, optional_keys, callback_fn, as_half, to_host=True):
     if callback_fn is not None:
         pred = {**callback_fn(pred, data), **pred}
     if keys != "*":
@@ -58,6 +87,8 @@ def _process(model, data, keys, optional_keys, callback_fn, as_half):
             idx = k.replace("keypoints", "")
             scales = 1.0 / (data["scales"] if len(idx) == 0 else data[f"view{idx}"]["scales"])
             pred[k] = pred[k] * scales[None]
+    if not to_host:
+        return pred
     rec = {k: v[0].cpu().numpy() for k, v in pred.items()}  # .cpu() waits for this thread's stream only
     if as_half:
         rec = {k: (v.astype(np.float16) if v.dtype == np.float32 else v) for k, v in rec.items()}
@@ -116,8 +147,9 @@ def _merge_parts(output_file, world):
 
 @torch.no_grad()
 def export_predictions(loader, model, output_file, as_half=False, keys="*", callback_fn=None, optional_keys=(),
-                       workers=1, rank=None, world=None):
-    """rank / world (default: the torch.distributed process group, if one is initialised): the pair list is shared
+                       workers=1, rank=None, world=None, pair_batch=1):
+    """pair_batch: number of consecutive pairs processed by one `model.forward_pairs` call (module docstring).
+    rank / world (default: the torch.distributed process group, if one is initialised): the pair list is shared
     out round-robin over the ranks (one process per GPU, no data-path collective); every rank writes a part file
     next to `output_file`, and after one barrier rank 0 merges them into the single prediction file the evaluation
     reads (records in loader order, as the single-process loop writes them).  All ranks return `output_file`."""
@@ -140,7 +172,7 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
         try:
             local = []
             _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half,
-                         workers, local)
+                         workers, local, pair_batch)
             flat = {f"{idx}|{name}/{k}": v for idx, name, rec in local for k, v in rec.items()}
             with open(inner, "wb") as fh:
                 np.savez(fh, **flat)
@@ -167,7 +199,8 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
             raise RuntimeError("export_predictions: merging the part files failed on rank 0")
         return output_file
     local = []
-    _export_loop(enumerate(loader), model, device, keys, optional_keys, callback_fn, as_half, workers, local)
+    _export_loop(enumerate(loader), model, device, keys, optional_keys, callback_fn, as_half, workers, local,
+                 pair_batch)
     records = {}
     for _, name, rec in sorted(local, key=lambda e: e[0]):
         if name not in records:  # like the reference: a duplicate group name is skipped
@@ -186,51 +219,68 @@ def _any_rank_failed(failed_here: bool, device) -> bool:
     return bool(flag.item())
 
 
-def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out):
+def _batches(indexed, n):
+    """Lists of up to n consecutive (index, item) entries."""
+    chunk = []
+    for entry in indexed:
+        chunk.append(entry)
+        if len(chunk) == n:
+            yield chunk
+            chunk = []
+    if chunk:
+        yield chunk
+
+
+def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out, pair_batch=1):
     """Process (index, item) pairs; appends (index, name, record) to `out`."""
+    pair_batch = max(1, int(pair_batch or 1))
+
+    def run_chunk(replica, chunk):
+        """-> [(index, name, record)] of up to pair_batch consecutive items"""
+        datas = [_to_device(d, device) for _, d in chunk]
+        names = [d.get("name", [None])[0] for d in datas]
+        if len(datas) == 1:
+            recs = [_process(replica, datas[0], keys, optional_keys, callback_fn, as_half)]
+        else:
+            recs = _process_batch(replica, datas, keys, optional_keys, callback_fn, as_half)
+        return [(idx, name, rec) for (idx, _), name, rec in zip(chunk, names, recs)]
+
     if workers <= 1 or device == "cpu":
-        for idx, data_ in indexed:
-            data = _to_device(data_, device)
-            name = data.get("name", [None])[0]
-            out.append((idx, name, _process(model, data, keys, optional_keys, callback_fn, as_half)))
+        for chunk in _batches(indexed, pair_batch):
+            out.extend(run_chunk(model, chunk))
         return
 
-    # ---- `workers` pairs in flight: one thread + one HIP stream + one model replica each ----
+    # ---- `workers` chunks in flight: one thread + one HIP stream + one model replica each ----
     replicas = [model] + [_replicate(model) for _ in range(workers - 1)]
     tasks: "queue.Queue" = queue.Queue(maxsize=2 * workers)
-    results, errors = {}, []
+    results, errors = [], []
 
     def run(replica):
         stream = torch.cuda.Stream(device)
         with torch.no_grad(), torch.cuda.stream(stream):
             while True:
-                item = tasks.get()
-                if item is None:
+                chunk = tasks.get()
+                if chunk is None:
                     return
-                idx, data_ = item
                 try:
-                    data = _to_device(data_, device)
-                    results[idx] = (data.get("name", [None])[0],
-                                    _process(replica, data, keys, optional_keys, callback_fn, as_half))
+                    results.extend(run_chunk(replica, chunk))  # list.extend is atomic under the GIL
                 except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
                     errors.append(e)
 
     threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in replicas]
     for t in threads:
         t.start()
-    for idx, data_ in indexed:
+    for chunk in _batches(indexed, pair_batch):
         if errors:
             break
-        tasks.put((idx, data_))
+        tasks.put(chunk)
     for _ in threads:
         tasks.put(None)
     for t in threads:
         t.join()
     if errors:
         raise errors[0]
-    for idx in sorted(results):
-        name, rec = results[idx]
-        out.append((idx, name, rec))
+    out.extend(sorted(results, key=lambda e: e[0]))
 
 
 def _write(path: Path, records: dict):

@@ -387,6 +387,116 @@ class LightGlue(nn.Module):
             "prune1": torch.full_like(ms1, conf.n_layers),
         }
 
+    # -- several pairs of DIFFERENT sizes through one launch sequence -----------------------------
+    def forward_pairs(self, items: list) -> list:
+        """MI355X addition: `[self(d) for d in items]` (each `d` a batch-1 input of `forward`) as ONE matcher pass.
+        The reference's evaluation loop calls the matcher pair by pair only because the images of an HPatches-style
+        list differ in size (utils/export_predictions.py:36-45, datasets/hpatches.py:60); LightGlue does not care
+        about image sizes once the key points exist, so pairs with their own key-point counts run together through
+        gfc_lg_forward_ragged: the layers over all rows at once, the assignment head per group of equal-shape pairs.
+        Same arithmetic per pair; results are returned per pair in the order given.  Pairs without key points in one
+        view, adaptive depth / width and batch sizes other than 1 take the single-pair path."""
+        conf = self.conf
+        adaptive = conf.depth_confidence > 0 or conf.width_confidence > 0
+        outs = [None] * len(items)
+        rag = []
+        for i, data in enumerate(items):
+            for key in self.required_data_keys:
+                assert key in data, f"Missing key {key} in data"
+            k0, k1 = data["keypoints0"], data["keypoints1"]
+            if adaptive or k0.shape[0] != 1 or k0.shape[1] == 0 or k1.shape[1] == 0 or self.training:
+                outs[i] = self(data)
+            else:
+                rag.append(i)
+        for c in range(0, len(rag), nat.GFC_LG_MAX_RAGGED_PAIRS):
+            chunk = rag[c:c + nat.GFC_LG_MAX_RAGGED_PAIRS]
+            for i, out in zip(chunk, self._forward_ragged([items[i] for i in chunk])):
+                outs[i] = out
+        return outs
+
+    def _forward_ragged(self, items):
+        conf, lib = self.conf, nat.lib()
+        if not self.are_weights_initialized:
+            raise RuntimeError("LightGlue weights are not loaded (conf.weights or load_state_dict)")
+        device = items[0]["keypoints0"].device
+        nat.require_cuda(items[0]["keypoints0"], "data['keypoints0']")
+        if self._packed is None or self._packed[2] != device:
+            self._packed = self._pack(device)
+            self._graphs = {}
+        d, din = conf.descriptor_dim, conf.input_dim
+        # equal shapes next to each other (stable): every run of equal (m, n) is one batched assignment head
+        shapes = [(int(it["keypoints0"].shape[1]), int(it["keypoints1"].shape[1])) for it in items]
+        order = sorted(range(len(items)), key=lambda i: shapes[i])
+        kp_parts, de_parts, so_parts, s0, s1 = [], [], [], [], []
+        g = 0
+        while g < len(order):
+            h = g
+            while h < len(order) and shapes[order[h]] == shapes[order[g]]:
+                h += 1
+            for side in ("0", "1"):
+                for i in order[g:h]:
+                    it = items[i]
+                    kp = it["keypoints" + side][0].float()
+                    de = it["descriptors" + side][0].float()
+                    assert de.shape[-1] == din
+                    kp_parts.append(kp)
+                    de_parts.append(de)
+                    if conf.add_scale_ori:
+                        sc, ori = it["scales" + side][0], it["oris" + side][0]
+                        so_parts.append(torch.stack([sc.reshape(-1), ori.reshape(-1)], -1).float())
+            g = h
+        for i in order:
+            it = items[i]
+            for side, acc in (("0", s0), ("1", s1)):
+                size = it.get("view" + side, {}).get("image_size")
+                kp = it["keypoints" + side]
+                if size is None:  # normalize_keypoints without a size: the extent of the key points (lightglue.py:31-32)
+                    size = 1 + kp.float().amax(-2) - kp.float().amin(-2)
+                acc.append(torch.as_tensor(size, device=device, dtype=torch.float32).reshape(-1, 2)[:1])
+        b = len(order)
+        kp = torch.cat(kp_parts, 0).contiguous()
+        de = torch.cat(de_parts, 0).contiguous()
+        so = torch.cat(so_parts, 0).contiguous() if so_parts else None
+        size0, size1 = torch.cat(s0, 0).contiguous(), torch.cat(s1, 0).contiguous()
+        ms = [shapes[i][0] for i in order]
+        ns = [shapes[i][1] for i in order]
+        cm, cn = (ctypes.c_int32 * b)(*ms), (ctypes.c_int32 * b)(*ns)
+        sm, sn = sum(ms), sum(ns)
+        m0 = torch.empty((sm,), device=device, dtype=torch.long)
+        m1 = torch.empty((sn,), device=device, dtype=torch.long)
+        sc0, sc1 = torch.empty((sm,), device=device), torch.empty((sn,), device=device)
+        scores = torch.empty((sum((a + 1) * (c + 1) for a, c in zip(ms, ns)),), device=device)
+        rows = torch.empty((sm + sn, d), device=device)
+        ws = self._ws.get(lib.gfc_lg_ragged_workspace_bytes(b, cm, cn), device)
+        nat.check(lib.gfc_lg_forward_ragged(
+            ctypes.byref(self._packed[0]), nat.ptr(kp), nat.ptr(de), nat.ptr(size0), nat.ptr(size1), nat.ptr(so), b, cm,
+            cn, float(conf.filter_threshold), nat.ptr(m0), nat.ptr(m1), nat.ptr(sc0), nat.ptr(sc1), nat.ptr(scores),
+            nat.ptr(rows), nat.ptr(ws), ws.numel(), ctypes.byref(self.trace.c) if self.trace is not None else None,
+            nat.stream_ptr(device)), "gfc_lg_forward_ragged")
+        # per-pair views of the flat outputs; rows: group after group, side 0 then side 1 inside a group
+        outs = [None] * b
+        o0 = o1 = os_ = r = 0
+        g = 0
+        while g < b:
+            h = g
+            while h < b and (ms[h], ns[h]) == (ms[g], ns[g]):
+                h += 1
+            m, n, cnt = ms[g], ns[g], h - g
+            for j in range(cnt):
+                ms0_, ms1_ = sc0[o0:o0 + m].view(1, m), sc1[o1:o1 + n].view(1, n)
+                outs[order[g + j]] = {
+                    "matches0": m0[o0:o0 + m].view(1, m), "matches1": m1[o1:o1 + n].view(1, n),
+                    "matching_scores0": ms0_, "matching_scores1": ms1_,
+                    "ref_descriptors0": rows[r + j * m: r + (j + 1) * m].view(1, 1, m, d),
+                    "ref_descriptors1": rows[r + cnt * m + j * n: r + cnt * m + (j + 1) * n].view(1, 1, n, d),
+                    "log_assignment": scores[os_:os_ + (m + 1) * (n + 1)].view(1, m + 1, n + 1),
+                    "prune0": torch.full_like(ms0_, conf.n_layers), "prune1": torch.full_like(ms1_, conf.n_layers),
+                }
+                o0, o1, os_ = o0 + m, o1 + n, os_ + (m + 1) * (n + 1)
+            r += cnt * (m + n)
+            g = h
+        return outs
+
     # -- adaptive depth / width (lightglue.py:500-521,555-580) -----------------------------------
     def _forward_adaptive(self, kpts0, kpts1, desc0, desc1, size0, size1, so0=None, so1=None):
         """Early stopping (`depth_confidence`) and point pruning (`width_confidence`); batch size 1 like the

@@ -53,6 +53,13 @@ class LightGlue(BaseModel):
         # in-tree contract takes the same tensors under the pipeline's own keys
         return self.net(data)
 
+    def forward_pairs(self, items):
+        """Several batch-1 inputs of different sizes through one matcher pass (lightglue.LightGlue.forward_pairs)."""
+        for data in items:
+            for key in self.required_data_keys:
+                assert key in data, f"Missing key {key} in data"
+        return self.net.forward_pairs(items)
+
     def loss(self, pred, data):
         raise NotImplementedError
 

@@ -14,7 +14,7 @@ from torch import nn
 
 from . import _native as nat
 from . import weights as _weights
-from ._superpoint_common import joint_pair_data, SAMPLE_FIXED, SAMPLE_LEGACY, PackedSuperPoint, SuperPointRunner, run_extractor
+from ._superpoint_common import RaggedCounts, extract_views, joint_pair_data, SAMPLE_FIXED, SAMPLE_LEGACY, PackedSuperPoint, SuperPointRunner, run_extractor
 from .base_model import BaseModel, conf_get
 
 _LAYERS = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"]
@@ -132,8 +132,19 @@ class SuperPoint(BaseModel):
         if b == 1:  # the two views may yield different numbers of key points
             preds = self._forward(joint, per_image=True)
             return preds[0], preds[1]
-        pred = self._forward(joint)  # batched views: one count for all images, as in a single-view call
+        try:
+            pred = self._forward(joint)  # batched views: one count for all 2b images
+        except RaggedCounts:
+            # without padding the counts need only agree INSIDE a view (the reference runs one call per view)
+            return self(data0), self(data1)
         return {k: v[:b] for k, v in pred.items()}, {k: v[b:] for k, v in pred.items()}
+
+    def forward_views(self, views):
+        """Single-image inputs of DIFFERENT image shapes -> their predictions, one extractor call per distinct shape
+        (_superpoint_common.extract_views).  MI355X addition used by TwoViewPipeline.forward_pairs."""
+        if not conf_get(self.conf, "sparse_outputs"):
+            return [self(v) for v in views]
+        return extract_views(self, views)
 
     def loss(self, pred, data):
         raise NotImplementedError

@@ -33,3 +33,30 @@ def synthetic_pairs(n_pairs: int, height: int = 480, width: int = 640, seed: int
     v0 = synthetic_images(n_pairs, height, width, seed, device="cpu")
     v1 = shift_image(v0, dx, dy)
     return v0.to(device), v1.to(device)
+
+
+HPATCHES_LIKE_SHAPES = [(480, 640), (480, 613), (640, 480), (725, 480), (480, 656)]  # (h, w): short side 480
+
+
+def hpatches_shaped_pairs(n_pairs: int, seed: int = 4000, device="cpu", per_sequence: int = 5):
+    """`n_pairs` loader items shaped like the HPatches evaluation list (BASELINE config 3; datasets/hpatches.py:94-112:
+    RGB, short side resized to 480, arbitrary long side, batch 1, `scales` = new / original size): sequences of
+    `per_sequence` pairs share view 0's image shape (the sequence's reference image), view 1's shape changes from item
+    to item.  Both views are crops of one band-limited canvas displaced by (24, 16) pixels, so that true
+    correspondences exist."""
+    items = []
+    for i in range(n_pairs):
+        s0 = HPATCHES_LIKE_SHAPES[(i // per_sequence) % len(HPATCHES_LIKE_SHAPES)]
+        s1 = HPATCHES_LIKE_SHAPES[(i * 2 + 1) % len(HPATCHES_LIKE_SHAPES)]
+        canvas = synthetic_images(1, 760, 680, seed=seed + i)[0, 0]
+        views = {}
+        for tag, (h, w), (y, x), up in (("view0", s0, (0, 0), 2.0), ("view1", s1, (16, 24), 1.5)):
+            g = canvas[y:y + h, x:x + w]
+            rgb = torch.stack([g * 0.8, g, g * 0.9], 0).clamp(0, 1)
+            rgb = ((rgb * 255).round() / 255).float()[None]  # what a decoded uint8 image gives
+            ow, oh = int(w * up), int(h * up)
+            views[tag] = {"image": rgb.to(device), "image_size": torch.tensor([[float(w), float(h)]], device=device),
+                          "scales": torch.tensor([[w / ow, h / oh]], dtype=torch.float32, device=device),
+                          "original_image_size": torch.tensor([[float(ow), float(oh)]], device=device)}
+        items.append({"name": [f"synth{i // per_sequence}/{i % per_sequence + 2}.ppm"], **views})
+    return items

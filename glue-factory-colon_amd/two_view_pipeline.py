@@ -108,11 +108,7 @@ class TwoViewPipeline(BaseModel):
 
     def _forward(self, data):
         image0, image1 = data["view0"]["image"], data["view1"]["image"]
-        device, b = image0.device, image0.shape[0]
-
-        def full(v):
-            return torch.full((b,), float(v), device=device, dtype=torch.float32)
-
+        device = image0.device
         joint = self.extract_pair(data) if conf_get(self.conf, "joint_extraction", True) else None
         if joint is not None:
             pred0, pred1, t0, c0, c1, mem0 = joint
@@ -125,6 +121,16 @@ class TwoViewPipeline(BaseModel):
         if hasattr(self, "matcher"):
             out, t_match, mem_match = self._timed(device, lambda: self.matcher({**data, **pred}))
             pred = {**pred, **out}
+        return self._with_timing_keys(pred, image0, image1, (t0, t1), (c0, c1), (mem0, mem1), t_match, mem_match)
+
+    def _with_timing_keys(self, pred, image0, image1, ext_t, ext_core, ext_mem, t_match, mem_match):
+        """The timing / memory / resolution keys of two_view_pipeline.py:286-339 on a pair's prediction."""
+        device, b = image0.device, image0.shape[0]
+        (t0, t1), (c0, c1), (mem0, mem1) = ext_t, ext_core, ext_mem
+
+        def full(v):
+            return torch.full((b,), float(v), device=device, dtype=torch.float32)
+
         ext_times = [t for t in (t0, t1) if t is not None]
         if ext_times:
             pred["extractor_time_ms"] = full(sum(ext_times))
@@ -145,6 +151,47 @@ class TwoViewPipeline(BaseModel):
             pred["matcher_memory_mb"] = full(mem_match)
         pred["pair_resolution"] = full(image0.shape[-2] * image0.shape[-1] + image1.shape[-2] * image1.shape[-1])
         return pred
+
+    def forward_pairs(self, datas):
+        """MI355X addition: `[self(d) for d in datas]` for batch-1 pairs whose IMAGES DIFFER IN SIZE (the HPatches
+        evaluation list: datasets/hpatches.py:60 asserts batch size 1, utils/export_predictions.py:36-45 runs the model
+        pair by pair) with both stages batched: the extractor once per distinct image shape among the 2N views
+        (`forward_views`), the matcher ONCE over all N pairs with their own key-point counts (`forward_pairs`,
+        gfc_lg_forward_ragged).  Every pair's prediction carries the keys of the single-pair call; the timing /
+        memory keys are the batch's figures divided by N (one device-synchronised measurement per stage and batch).
+        Pairs with cached features, batched pairs, or components without the batched entry points take `self(d)`."""
+        ext, mat = getattr(self, "extractor", None), getattr(self, "matcher", None)
+        ok = (len(datas) > 1 and ext is not None and hasattr(ext, "forward_views")
+              and (mat is None or hasattr(mat, "forward_pairs")))
+        for d in datas:
+            for key in self.required_data_keys:
+                assert key in d, f"Missing key {key} in data"
+            ok = ok and not d["view0"].get("cache") and not d["view1"].get("cache") \
+                and d["view0"]["image"].shape[0] == 1 and d["view1"]["image"].shape[0] == 1
+        if not ok:
+            return [self(d) for d in datas]
+        n = len(datas)
+        device = datas[0]["view0"]["image"].device
+        views = [d[f"view{i}"] for d in datas for i in ("0", "1")]
+        vpreds, t_ext, mem_ext = self._timed(device, lambda: ext.forward_views(views))
+        cores = [vp.pop("extractor_core_time_ms", None) for vp in vpreds]
+        preds = []
+        for j, d in enumerate(datas):
+            p0, p1 = vpreds[2 * j], vpreds[2 * j + 1]
+            preds.append({**{k + "0": v for k, v in p0.items()}, **{k + "1": v for k, v in p1.items()}})
+        t_match = mem_match = None
+        if mat is not None:
+            outs, t_match, mem_match = self._timed(device, lambda: mat.forward_pairs(
+                [{**d, **p} for d, p in zip(datas, preds)]))
+            preds = [{**p, **o} for p, o in zip(preds, outs)]
+
+        def share(v):
+            return None if v is None else v / n
+
+        return [self._with_timing_keys(p, d["view0"]["image"], d["view1"]["image"], (share(t_ext), None),
+                                       (cores[2 * j], cores[2 * j + 1]), (share(mem_ext), None), share(t_match),
+                                       share(mem_match))
+                for j, (d, p) in enumerate(zip(datas, preds))]
 
     def loss(self, pred, data):
         raise NotImplementedError("training is out of scope")

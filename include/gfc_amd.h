@@ -420,6 +420,25 @@ int gfc_lg_forward_packed(const gfc_lg_params* p, const float* kpts, const float
                           int64_t* m1, float* ms0, float* ms1, float* log_assignment, float* rows, void* ws,
                           size_t ws_bytes, gfc_trace* attention_trace, void* stream);
 
+/* The same matcher over B pairs with THEIR OWN key-point counts (m[i], n[i] > 0, host arrays, B <=
+ * GFC_LG_MAX_RAGGED_PAIRS): the regime of the reference's evaluation loop, which calls the matcher once per pair only
+ * because the IMAGES of an HPatches-style list differ in size (gluefactory/utils/export_predictions.py:36-45,
+ * datasets/hpatches.py:60) -- LightGlue itself is image-size independent once the key points exist.  One launch
+ * sequence for all pairs: the layers run over all rows at once (the attention kernel takes a per-problem table
+ * anyway), the assignment head once per GROUP = maximal run of consecutive pairs with equal (m, n).
+ * Row layout of kpts [R,2] / desc [R,Din] / scale_ori [R,2] / rows [R,256], R = sum(m) + sum(n): group after group,
+ * inside a group the side-0 rows of its pairs (pair-major) followed by their side-1 rows -- i.e. every group is laid out
+ * as gfc_lg_forward_packed lays out a uniform batch (B equal pairs = one group = exactly that function's layout).
+ * Outputs are flat, in pair order: m0 / ms0 [sum m], m1 / ms1 [sum n], log_assignment [sum (m+1)(n+1)] (pair i's
+ * [m+1, n+1] matrix contiguous).  size0 / size1 [B,2] (device).  No allocation, no synchronisation; the counts travel
+ * to the device as kernel arguments.  Same arithmetic per pair as gfc_lg_forward_packed (lightglue.py:422-553). */
+#define GFC_LG_MAX_RAGGED_PAIRS 128
+size_t gfc_lg_ragged_workspace_bytes(int B, const int32_t* m, const int32_t* n);
+int gfc_lg_forward_ragged(const gfc_lg_params* p, const float* kpts, const float* desc, const float* size0,
+                          const float* size1, const float* scale_ori, int B, const int32_t* m, const int32_t* n,
+                          float threshold, int64_t* m0, int64_t* m1, float* ms0, float* ms1, float* log_assignment,
+                          float* rows, void* ws, size_t ws_bytes, gfc_trace* attention_trace, void* stream);
+
 /* Nearest-neighbour matcher ("next" row; the matcher of the reference's superpoint+NN configurations):
  * sim = desc0 . desc1^T, top-2 per row / column, ratio test d1 <= ratio^2 d2 and distance test d1 <= th^2 on
  * d = 2(1 - sim) (thresholds <= 0 disable a test), optional mutual check; matching scores are 0/1;

@@ -351,31 +351,35 @@ def golden_pipeline():
 
 
 # --------------------------------------------------- C3: superpoint+lightglue-official, HPatches-shaped
-from c3_inputs import C3_PAIRS, c3_pair  # noqa: E402  (tests/golden/c3_inputs.py: shared with the GPU test)
+from c3_inputs import C3_PAIRS, C3_RAGGED_PAIRS, C3_RAGGED_THRESHOLD, c3_pair  # noqa: E402  (shared with the GPU test)
 
 
-def golden_pipeline_official():
-    """BASELINE config 3 (superpoint+lightglue-official.yaml:3-13,27-33: gluefactory_nonfree.superpoint, 1024 key
-    points, threshold 0, NMS 3 + LightGlue, filter 0.1) through the reference's TwoViewPipeline, b = 1, one record per
-    pair exactly as utils/export_predictions.py:36-85 writes it: export keys of eval/hpatches.py:61-68, key points
-    multiplied by 1 / scales (:55-61).  The official extractor's constructor fetch is redirected to the generated
-    weights; `matchers.lightglue_pretrained` needs the third-party package, so the in-tree matcher (same architecture,
-    same checkpoints) stands in for it, as everywhere else."""
+def _official_pipeline(detection_threshold):
+    """The reference's TwoViewPipeline in the superpoint+lightglue-official configuration (the official extractor's
+    constructor fetch redirected to the generated weights; the in-tree matcher stands in for `lightglue_pretrained`,
+    which needs the third-party package: same architecture, same checkpoints)."""
     sd = weights.superpoint_state_dict(0)
     orig = torch.hub.load_state_dict_from_url
     torch.hub.load_state_dict_from_url = lambda *a, **k: sd
     try:
         pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": 1024,
-                                              "detection_threshold": 0.0, "nms_radius": 3},
+                                              "detection_threshold": detection_threshold, "nms_radius": 3},
                                 "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "flash": False,
                                             "depth_confidence": -1, "width_confidence": -1}}).eval()
     finally:
         torch.hub.load_state_dict_from_url = orig
     pipe.matcher.load_state_dict(weights.lightglue_state_dict(0), strict=False)
+    return pipe
+
+
+def _official_records(pipe, pairs):
+    """One record per pair exactly as utils/export_predictions.py:36-85 writes it: export keys of
+    eval/hpatches.py:61-68 (+ the optional score keys), key points multiplied by 1 / scales (:55-61)."""
     export_keys = ["keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1",
-                   "keypoint_scores0", "keypoint_scores1"]  # eval/hpatches.py:61-68 + the optional score keys
-    out = {"names": np.array([n for n, *_ in C3_PAIRS])}
-    for i, (name, seed, s0, s1, origs) in enumerate(C3_PAIRS):
+                   "keypoint_scores0", "keypoint_scores1"]
+    out = {"names": np.array([n for n, *_ in pairs])}
+    counts = []
+    for i, (name, seed, s0, s1, origs) in enumerate(pairs):
         data = c3_pair(seed, s0, s1, origs)
         pred = pipe(data)
         rec = {k: pred[k] for k in export_keys}
@@ -383,9 +387,25 @@ def golden_pipeline_official():
             rec[k] = rec[k] * (1.0 / data["view" + k[-1]]["scales"])[None]
         for k, v in rec.items():
             out[f"p{i}_{k}"] = npy(v[0])
-        print(name, "kpts", rec["keypoints0"].shape[1], rec["keypoints1"].shape[1], "matches",
-              int((rec["matches0"] >= 0).sum()))
+        counts.append((rec["keypoints0"].shape[1], rec["keypoints1"].shape[1]))
+        print(name, "kpts", *counts[-1], "matches", int((rec["matches0"] >= 0).sum()))
+    return out, counts
+
+
+def golden_pipeline_official():
+    """BASELINE config 3 (superpoint+lightglue-official.yaml:3-13,27-33: gluefactory_nonfree.superpoint, 1024 key
+    points, threshold 0, NMS 3 + LightGlue, filter 0.1) through the reference's TwoViewPipeline, b = 1."""
+    out, _ = _official_records(_official_pipeline(0.0), C3_PAIRS)
     save("pipeline_official", **out)
+
+
+def golden_pipeline_official_ragged():
+    """The same configuration with `detection_threshold` raised so that views keep FEWER than 1024 key points and the
+    two views of a pair keep different numbers: the official extractor's ragged path at config-3 sizes."""
+    out, counts = _official_records(_official_pipeline(C3_RAGGED_THRESHOLD), C3_RAGGED_PAIRS)
+    assert any(a != b and max(a, b) < 1024 for a, b in counts), counts  # a pair with two different counts below the cap
+    assert any(max(a, b) == 1024 for a, b in counts) and any(min(a, b) < 1024 for a, b in counts), counts
+    save("pipeline_official_ragged", **out)
 
 
 def golden_boat_native():
@@ -518,6 +538,9 @@ if __name__ == "__main__":
     if "--only-official-pipeline" in sys.argv:
         golden_pipeline_official()
         sys.exit(0)
+    if "--only-official-ragged" in sys.argv:
+        golden_pipeline_official_ragged()
+        sys.exit(0)
     if "--only-boat-native" in sys.argv:
         golden_boat_native()
         sys.exit(0)
@@ -542,4 +565,5 @@ if __name__ == "__main__":
     golden_lightglue()
     golden_pipeline()
     golden_pipeline_official()
+    golden_pipeline_official_ragged()
     golden_boat_native()

@@ -40,8 +40,13 @@ def _key(kp):
 
 
 def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, tie_tol=2e-6, score_tol=1e-5,
-                      desc_tol=1e-4, max_flip_frac=0.0):
-    """kp [N,2], sc [N], desc [N,D] (HIP) vs reference lists.  Returns (idx_mine, idx_ref) of the common points."""
+                      desc_tol=1e-4, max_flips=0, swap_tol=5e-6):
+    """kp [N,2], sc [N], desc [N,D] (HIP) vs reference lists.  Returns (idx_mine, idx_ref) of the common points.
+    max_flips: key points allowed to differ between the two lists (measured 0 on every case of the suite since round 1;
+    a test that ever observes one states its allowance explicitly) -- each must still be EXPLAINED below.
+    swap_tol: every ORDER difference must be a near tie: a common point that sits at another rank than in the
+    reference has, by the reference's own scores, a score within swap_tol of the point whose rank it took (fp32
+    accumulation order of the convolutions against mkldnn's; the top-k order is by score)."""
     kp, sc, desc = kp.cpu(), sc.cpu(), desc.cpu()
     assert kp.shape == ref_kp.shape, (kp.shape, ref_kp.shape)  # counts are exact
     mine = {k: i for i, k in enumerate(_key(kp))}
@@ -51,9 +56,7 @@ def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, ti
     im = torch.tensor([mine[k] for k in common], dtype=torch.long)
     ir = torch.tensor([ref[k] for k in common], dtype=torch.long)
     n_flip = len(ref) - len(common)
-    # measured on every case of the suite (profiles/r02_parity_stats.json): 0 flips.  One flip stays admissible -- it
-    # must still be EXPLAINED below as a near tie at the selection boundary or inside one NMS window.
-    assert n_flip <= max_flip_frac * max(len(ref), 1) + 1, f"{name}: {n_flip} of {len(ref)} key points differ"
+    assert n_flip <= max_flips, f"{name}: {n_flip} of {len(ref)} key points differ"
     s_err = (sc[im] - ref_sc[ir]).abs().max().item() if len(common) else 0.0
     d_err = (desc[im] - ref_desc[ir]).abs().max().item() if len(common) else 0.0
     assert s_err < score_tol, (name, s_err)
@@ -67,8 +70,18 @@ def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, ti
         moved = any((kp[i] - ref_kp[j]).abs().max().item() <= radius + 0.5
                     and abs(sc[i].item() - ref_sc[j].item()) <= score_tol for i in only_mine)
         assert near_boundary or moved, f"{name}: unexplained key-point difference at {ref_kp[j].tolist()}"
-    swaps = int((im != ir).sum().item())
-    record(name, n=len(ref), flips=n_flip, order_swaps=swaps, score_err=s_err, desc_err=d_err)
+    # explain every order swap: rank among the common points (robust to a flip shifting absolute positions)
+    swaps, max_gap = 0, 0.0
+    if len(common):
+        rank_mine = torch.empty_like(im)
+        rank_mine[im.argsort()] = torch.arange(len(im))  # common point t sits at rank rank_mine[t] of MY list
+        moved_t = (rank_mine != torch.arange(len(im))).nonzero().flatten()
+        swaps = int(moved_t.numel())
+        if swaps:
+            gaps = (ref_sc[ir[moved_t]] - ref_sc[ir[rank_mine[moved_t]]]).abs()
+            max_gap = float(gaps.max())
+            assert max_gap < swap_tol, f"{name}: order swap between reference scores {max_gap:.3g} apart"
+    record(name, n=len(ref), flips=n_flip, order_swaps=swaps, max_swap_gap=max_gap, score_err=s_err, desc_err=d_err)
     return im, ir
 
 

@@ -93,6 +93,62 @@ def test_export_predictions_contract(tmp_path, monkeypatch):
     assert half["v_seq/2.ppm"]["keypoints0"].dtype == np.float16 and half["v_seq/2.ppm"]["matches0"].dtype == np.int64
 
 
+def test_export_predictions_pair_batch_host_logic(tmp_path, monkeypatch):
+    """`pair_batch` on the host side (no GPU): consecutive loader items reach `model.forward_pairs` in chunks of N (the
+    last one shorter), a model without that entry point is called pair by pair, records come out in loader order with
+    the single-pair layout (keys filtered, key points divided by `scales`, one host copy per dtype and batch)."""
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: False)
+
+    class Ragged(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.chunks = []
+
+        def one(self, data):
+            n = int(data["view0"]["n"])  # every pair its own number of key points
+            return {"keypoints0": torch.arange(n * 2, dtype=torch.float32).reshape(1, n, 2) + 1,
+                    "keypoints1": torch.ones(1, n + 1, 2), "matches0": torch.arange(n)[None] - 1,
+                    "matching_scores0": torch.full((1, n), 0.5), "descriptors0": torch.zeros(1, n, 4)}
+
+        def forward(self, data):
+            self.chunks.append(1)
+            return self.one(data)
+
+        def forward_pairs(self, datas):
+            self.chunks.append(len(datas))
+            return [self.one(d) for d in datas]
+
+    def loader():
+        for i in range(7):
+            yield {"name": [f"s/{i}.ppm"], "view0": {"image": torch.zeros(1, 1, 8, 8), "n": torch.tensor(3 + i),
+                                                     "scales": torch.tensor([[0.5, 0.25]])},
+                   "view1": {"image": torch.zeros(1, 1, 8, 8), "scales": torch.tensor([[2.0, 1.0]])}}
+
+    keys = ["keypoints0", "keypoints1", "matches0", "matching_scores0"]
+    model = Ragged()
+    seq = ep.load_predictions(ep.export_predictions(loader(), model, tmp_path / "seq.npz", keys=keys))
+    assert model.chunks == [1] * 7
+    model.chunks.clear()
+    bat = ep.load_predictions(ep.export_predictions(loader(), model, tmp_path / "bat.npz", keys=keys, pair_batch=3))
+    assert model.chunks == [3, 3, 1]  # the trailing single pair takes the ordinary call
+    assert list(seq) == list(bat) == [f"s/{i}.ppm" for i in range(7)]
+    for name in seq:
+        assert list(seq[name]) == list(bat[name]) == keys
+        for k in keys:
+            assert seq[name][k].dtype == bat[name][k].dtype and np.array_equal(seq[name][k], bat[name][k]), (name, k)
+    assert np.allclose(bat["s/2.ppm"]["keypoints0"][0], [2.0, 8.0]) and bat["s/2.ppm"]["keypoints0"].shape == (5, 2)
+    half = ep.load_predictions(ep.export_predictions(loader(), model, tmp_path / "h.npz", keys=keys, pair_batch=4,
+                                                     as_half=True))
+    assert half["s/1.ppm"]["keypoints0"].dtype == np.float16 and half["s/1.ppm"]["matches0"].dtype == np.int64
+    with pytest.raises(ValueError, match="Missing key"):
+        ep.export_predictions(loader(), model, tmp_path / "bad.npz", keys=keys + ["lines0"], pair_batch=3)
+    # a model without forward_pairs: pair by pair, same records
+    plain = _FakeModel()
+    a = ep.load_predictions(ep.export_predictions(_loader(), plain, tmp_path / "a.npz"))
+    b = ep.load_predictions(ep.export_predictions(_loader(), plain, tmp_path / "b.npz", pair_batch=2))
+    assert all(np.array_equal(a[n][k], b[n][k]) for n in a for k in a[n])
+
+
 def test_cache_loader_round_trip(tmp_path):
     """export_predictions divides key points by `scales`, CacheLoader multiplies them back in
     (export_predictions.py:73-79, cache_loader.py:145-154): exported per-image features come back unchanged, padded

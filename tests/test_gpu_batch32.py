@@ -71,7 +71,7 @@ def test_c2_batch32_vs_oracle(c2_batch32):
         n_ref_total += len(theirs)
         n_same += len(mine & theirs)
         assert len(theirs) > 500
-        assert len(mine ^ theirs) <= 2, (i, len(mine), len(theirs), len(mine ^ theirs))
+        assert mine == theirs, (i, len(mine), len(theirs), len(mine ^ theirs))  # measured: identical since round 2
         # scores of the common matched pairs
         def by_pair(kp0, kp1, m0, s0):
             kp0, kp1, m0, s0 = kp0.cpu(), kp1.cpu(), m0.cpu(), s0.cpu()

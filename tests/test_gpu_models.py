@@ -127,7 +127,7 @@ def test_superpoint_open_extreme_sizes_vs_oracle(h, w, k):
                     detection_threshold=0.0)
     ours = set(map(tuple, p["keypoints"][0].cpu().tolist()))
     ref = set(map(tuple, o["keypoints"][0].tolist()))
-    assert len(ours ^ ref) <= (2 if k >= 1024 else 0), (len(ours), len(ref), len(ours ^ ref))  # top-k boundary ties
+    assert ours == ref, (len(ours), len(ref), len(ours ^ ref))  # measured: identical sets at every size
     assert p["descriptors"].shape == (1, len(ours), 256)
 
 
@@ -289,7 +289,7 @@ def lg_data(g, sl=slice(None), prefix=""):
             "view0": {"image_size": size}, "view1": {"image_size": size}}
 
 
-def check_lg(pred, g, tag, atol_la=2e-4):
+def check_lg(pred, g, tag, atol_la=1e-4):
     assert pred["matches0"].dtype == torch.int64
     assert torch.equal(pred["matches0"].cpu(), g[tag + "matches0"])
     assert torch.equal(pred["matches1"].cpu(), g[tag + "matches1"])
@@ -297,7 +297,7 @@ def check_lg(pred, g, tag, atol_la=2e-4):
     assert maxerr(pred["matching_scores1"], g[tag + "matching_scores1"]) < TOL
     la, ref = pred["log_assignment"].cpu(), g[tag + "log_assignment"]
     assert la.shape == ref.shape
-    assert ((la - ref).abs() <= atol_la + 1e-5 * ref.abs()).all(), (la - ref).abs().max()
+    assert ((la - ref).abs() <= atol_la * (1 + ref.abs())).all(), (la - ref).abs().max()  # north star: 1e-4 (values reach -100)
 
 
 def test_lightglue_golden(golden):
@@ -305,8 +305,8 @@ def test_lightglue_golden(golden):
     m = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
     pred = m(lg_data(g))
     check_lg(pred, g, "b2_")
-    assert maxerr(pred["ref_descriptors0"], g["b2_ref_descriptors0"]) < 2e-4
-    assert maxerr(pred["ref_descriptors1"], g["b2_ref_descriptors1"]) < 2e-4
+    assert maxerr(pred["ref_descriptors0"], g["b2_ref_descriptors0"]) < 1e-4
+    assert maxerr(pred["ref_descriptors1"], g["b2_ref_descriptors1"]) < 1e-4
     assert torch.equal(pred["prune0"].cpu(), g["b2_prune0"])
     m0 = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.0}).eval().to(DEV)
     pred = m0(lg_data(g))
@@ -367,7 +367,7 @@ def test_lightglue_add_scale_ori_golden(golden):
     out = m(data)
     assert torch.equal(out["matches0"].cpu(), g["matches0"]) and torch.equal(out["matches1"].cpu(), g["matches1"])
     assert maxerr(out["matching_scores0"], g["matching_scores0"]) < TOL
-    assert maxerr(out["ref_descriptors0"], g["ref_descriptors0"]) < 2e-4
+    assert maxerr(out["ref_descriptors0"], g["ref_descriptors0"]) < 1e-4
     with pytest.raises(KeyError):  # the inputs are required once the network is built for them
         m({k: v for k, v in data.items() if k != "oris1"})
 
@@ -605,8 +605,7 @@ def test_vga_1024_against_oracle(vga_case):
         mine = match_pairs(p["keypoints"][b], p["keypoints"][2 + b], pred["matches0"][b])
         theirs = match_pairs(okp[b], okp[2 + b], ref["matches0"][b])
         agree += len(mine & theirs)
-        # measured: identical pair sets (1485 of 1485); one explained key-point near-tie may move one pair
-        assert len(mine ^ theirs) <= 2, (len(mine), len(theirs), len(mine & theirs))
+        assert mine == theirs, (len(mine), len(theirs), len(mine & theirs))  # measured: identical (1485 of 1485)
     record("vga_k1024_matches", ref_matches=n_ref, agree=agree, log_assignment_rel_err=float(la_err))
     # size-independent properties
     m0, m1 = pred["matches0"], pred["matches1"]
@@ -663,7 +662,7 @@ def test_c4_pair_1024x1024_k2048_vs_oracle():
     ref = olg.match(weights.lightglue_state_dict(0), okp[:1], okp[1:], ode[:1], ode[1:], size, size, filter_threshold=0.1)
     mine = match_pairs(pred["keypoints0"][0], pred["keypoints1"][0], pred["matches0"][0])
     theirs = match_pairs(okp[0], okp[1], ref["matches0"][0])
-    assert len(theirs) > 1000 and len(mine ^ theirs) <= 2, (len(mine), len(theirs), len(mine ^ theirs))
+    assert len(theirs) > 1000 and mine == theirs, (len(mine), len(theirs), len(mine ^ theirs))
     record("c4_pair_vs_oracle", ref_matches=len(theirs), identical=len(mine & theirs))
 
 
@@ -706,12 +705,93 @@ def test_lg_forward_separate_arrays_equals_packed(golden):
     assert torch.equal(de0, d["descriptors0"].float()) and torch.equal(de1, d["descriptors1"].float())
 
 
+@pytest.mark.parametrize("dim", [256, 128])
+def test_lightglue_forward_pairs_ragged_equals_single_pair_calls(golden, dim):
+    """LightGlue.forward_pairs (gfc_lg_forward_ragged): pairs with THEIR OWN key-point counts through one launch sequence
+    give, pair by pair, what the single-pair call gives -- integer outputs identical, floats within 1e-4 (the kernels
+    chosen for a larger row count sum in another order) -- and a set of EQUAL pairs is one group, i.e. exactly the uniform
+    batched call.  Against the reference's vectors as well (lightglue.npz: `b2_` batch, `ragged_` pair, `d128_`)."""
+    g = golden("lightglue")
+    conf = {"weights": "synthetic", "filter_threshold": 0.1}
+    if dim == 128:
+        m = lightglue_pretrained.LightGlue({"features": "disk", **conf}).eval().to(DEV)
+        base = {"keypoints0": g["d128_keypoints0"].to(DEV), "keypoints1": g["d128_keypoints1"].to(DEV),
+                "descriptors0": g["d128_descriptors0"].to(DEV), "descriptors1": g["d128_descriptors1"].to(DEV)}
+        size = g["image_size"][:1].to(DEV)
+        items = [{**base, "view0": {"image_size": size}, "view1": {"image_size": size}}]
+    else:
+        m = lightglue.LightGlue(conf).eval().to(DEV)
+        d = lg_data(g)
+        items = [{k: (v[i:i + 1] if torch.is_tensor(v) else {"image_size": v["image_size"][i:i + 1]})
+                  for k, v in d.items()} for i in range(d["keypoints0"].shape[0])]
+    # ragged variants of the first pair: fewer points in view 0, in view 1, in both; and a second copy of an equal shape
+    first = items[0]
+    def cut(it, m0, n0):
+        return {**it, "keypoints0": it["keypoints0"][:, :m0].contiguous(), "descriptors0": it["descriptors0"][:, :m0].contiguous(),
+                "keypoints1": it["keypoints1"][:, :n0].contiguous(), "descriptors1": it["descriptors1"][:, :n0].contiguous()}
+    mm, nn_ = first["keypoints0"].shape[1], first["keypoints1"].shape[1]
+    items = items + [cut(first, 100, nn_), cut(first, mm, 77), cut(first, 33, 190), cut(first, 100, nn_), cut(first, 1, 5)]
+    single = [m(it) for it in items]
+    multi = m.forward_pairs(items)
+    assert len(multi) == len(items)
+    for i, (a, b) in enumerate(zip(single, multi)):
+        assert set(a) == set(b)
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, (i, k, a[k].shape, b[k].shape)
+        for k in ("matches0", "matches1", "prune0", "prune1"):
+            assert torch.equal(a[k], b[k]), (i, k)
+        for k in ("matching_scores0", "matching_scores1", "ref_descriptors0", "ref_descriptors1"):
+            assert maxerr(a[k], b[k].cpu()) < 1e-4, (i, k, maxerr(a[k], b[k].cpu()))
+        assert ((a["log_assignment"] - b["log_assignment"]).abs() <= 1e-4 * (1 + a["log_assignment"].abs())).all(), i
+    if dim == 256:  # reference vectors: the batch of two as two ragged-API pairs, and the 100-point pair
+        both = {k: torch.cat([multi[0][k], multi[1][k]], 0) for k in multi[0]}
+        check_lg(both, g, "b2_")
+        check_lg(multi[2], g, "ragged_")
+        # equal pairs = ONE group = the uniform batched call: bit-identical to it
+        uni = m(lg_data(g))
+        eq = m.forward_pairs(items[:2])
+        for k in uni:
+            assert torch.equal(uni[k], torch.cat([eq[0][k], eq[1][k]], 0)), k
+    else:
+        check_lg(multi[0], g, "d128_")
+
+
+def test_lightglue_forward_pairs_scale_ori_and_missing_sizes(golden):
+    """forward_pairs with `add_scale_ori` (4-d positional input, lightglue.py:436-453; reference vectors scale_ori.npz)
+    and with views that carry no image_size (normalisation by the key points' extent, lightglue.py:31-32)."""
+    g = golden("scale_ori")
+    m = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "add_scale_ori": True}).eval().to(DEV)
+    size = g["image_size"].to(DEV)
+    d = {k: g[k].to(DEV) for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1", "scales0", "scales1",
+                                   "oris0", "oris1")}
+    d.update({"view0": {"image_size": size}, "view1": {"image_size": size}})
+    items = [{k: (v[i:i + 1] if torch.is_tensor(v) else {"image_size": v["image_size"][i:i + 1]}) for k, v in d.items()}
+             for i in range(d["keypoints0"].shape[0])]
+    short = dict(items[0])
+    for k in ("keypoints0", "descriptors0", "scales0", "oris0"):
+        short[k] = short[k][:, :90].contiguous()
+    items.append(short)
+    single = [m(it) for it in items]
+    multi = m.forward_pairs(items)
+    for a, b in zip(single, multi):
+        assert torch.equal(a["matches0"], b["matches0"]) and torch.equal(a["matches1"], b["matches1"])
+        assert maxerr(a["matching_scores0"], b["matching_scores0"].cpu()) < 1e-4
+    assert torch.equal(torch.cat([p["matches0"] for p in multi[:-1]], 0).cpu(), g["matches0"])
+    m2 = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1}).eval().to(DEV)
+    bare = [{k: v for k, v in it.items() if k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1")}
+            for it in items]
+    for a, b in zip([m2(it) for it in bare], m2.forward_pairs(bare)):
+        assert torch.equal(a["matches0"], b["matches0"])
+        assert maxerr(a["matching_scores0"], b["matching_scores0"].cpu()) < 1e-4
+
+
 @pytest.mark.parametrize("variant", ["open", "official"])
-@pytest.mark.parametrize("threshold,k", [(0.0, 256), (0.001, 2000)])
+@pytest.mark.parametrize("threshold,k", [(0.0, 256), (0.001, 2000), (0.001, None)])
 def test_two_view_joint_extraction_equals_sequential(variant, threshold, k):
     """TwoViewPipeline with both views in ONE extractor call (`joint_extraction`, default) against the reference's order
     (view 0, then view 1; two_view_pipeline.py:283-284): every prediction tensor bit-identical.  The second case has
-    more slots than detections: the two views keep DIFFERENT numbers of key points (ragged per-image split)."""
+    more slots than detections: the two views keep DIFFERENT numbers of key points (ragged per-image split); the third
+    has `max_num_keypoints: None` (every detection above the threshold, H*W selection slots)."""
     name = "extractors.superpoint_open" if variant == "open" else "gluefactory_nonfree.superpoint"
     conf = {"extractor": {"name": name, "weights": "synthetic", "max_num_keypoints": k,
                           "detection_threshold": threshold, "nms_radius": 3},
@@ -721,9 +801,14 @@ def test_two_view_joint_extraction_equals_sequential(variant, threshold, k):
     data = {"view0": {"image": v0.to(DEV), "image_size": size}, "view1": {"image": v1.to(DEV), "image_size": size}}
     pj = TwoViewPipeline({**conf, "joint_extraction": True}).eval().to(DEV)(data)
     ps = TwoViewPipeline({**conf, "joint_extraction": False}).eval().to(DEV)(data)
-    if k > 1000:
+    if k is None or k > 1000:
         assert pj["keypoints0"].shape[1] != pj["keypoints1"].shape[1]  # the ragged case really is ragged
-        assert 0 < pj["keypoints0"].shape[1] < k
+        assert 0 < pj["keypoints0"].shape[1] < (k or 160 * 208)
+    if k is None:
+        # unlimited key points (superpoint_open's default): the selection has H*W slots per image; the ragged joint call
+        # samples descriptors for the largest COUNT only, not for all slots (a [2, H*W, 256] tensor kept alive by views)
+        n = max(pj["keypoints0"].shape[1], pj["keypoints1"].shape[1])
+        assert pj["descriptors0"].untyped_storage().nbytes() <= 2 * n * 256 * 4
     for key in ps:
         if key.endswith("_ms") or key.endswith("_mb"):
             continue
