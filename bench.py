@@ -245,6 +245,98 @@ def c3_regime(dev, n_pairs: int = 64):
                       "(two_view_pipeline.py:78-102), the other legs run with profile_calls: false"}
 
 
+def c4_shape(dev, pairs: int = 32, steps: int = 8, warmup: int = 2):
+    """Information only (never `value`): BASELINE configs[3]'s per-GPU shape -- 32 pairs of 1024 x 1024 images, 2048 key
+    points -- the same step as the headline workload, with the attention launches timed by HIP events."""
+    h = w = 1024
+    k = 2048
+    ext = superpoint_open.SuperPoint({"weights": "synthetic", "max_num_keypoints": k, "detection_threshold": 0.0,
+                                      "nms_radius": 3, "force_num_keypoints": True}).eval().to(dev)
+    mat = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "depth_confidence": -1,
+                               "width_confidence": -1}).eval().to(dev)
+    v0, v1 = synthetic.synthetic_pairs(pairs, h, w, seed=1234, device=dev)
+    size = torch.tensor([[float(w), float(h)]] * pairs, device=dev)
+    both = {"image": torch.cat([v0, v1], 0), "image_size": torch.cat([size, size], 0)}
+    del v0, v1
+
+    def step():
+        pj = ext(both)
+        return mat({"keypoints0": pj["keypoints"][:pairs], "keypoints1": pj["keypoints"][pairs:],
+                    "descriptors0": pj["descriptors"][:pairs], "descriptors1": pj["descriptors"][pairs:],
+                    "view0": {"image_size": size}, "view1": {"image_size": size}})
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            step()
+        atrace = nat.KernelTrace(2 * mat.conf.n_layers * steps)
+        mat.trace = atrace
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            pred = step()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+        mat.trace = None
+    adurs = atrace.durations_ms()
+    atrace.close()
+    prod = 2.0 * k * k * 64 * 4
+    n_self, n_cross = len(adurs[0::2]), len(adurs[1::2])
+    alg = n_self * 2 * pairs * 2 * prod + n_cross * pairs * 3 * prod
+    ach = alg / (sum(adurs) * 1e-3) / 1e12 if adurs else 0.0
+    return {"pairs_per_s": round(pairs * steps / dt, 2), "ms_per_step": round(dt / steps * 1e3, 2), "pairs_per_step": pairs,
+            "image": [h, w], "keypoints": k, "steps": steps, "mean_matches_per_pair": round(float((pred["matches0"] >= 0).sum()) / pairs, 1),
+            "attention": {"achieved_tflops": round(ach, 2), "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+                          "avg_launch_ms": round(sum(adurs) / max(len(adurs), 1), 4), "launches_timed": len(adurs),
+                          "share_of_step": round(sum(adurs) * 1e-3 / dt, 4),
+                          "definition": "as `roofline`: algorithmic attention FLOPs (one shared cross sim) / HIP-event time / 157.3"},
+            "pipeline_algorithmic_tflops": round(pairs * steps / dt * 580.6e9 / 1e12, 2)}
+
+
+def config5(dev, batch: int = 4, pairs: int = 8, iters: int = 6):
+    """Information only (never `value`): BASELINE configs[4] -- the DISK extractor (kornia's thin U-Net restated on HIP:
+    parity unpinned, kornia absent) at VGA, and DISK + LightGlue with 128-d descriptors."""
+    from glue_factory_colon_amd import disk_kornia, lightglue_pretrained
+
+    k = 2048
+    ext = disk_kornia.DISK({"weights": "synthetic", "max_num_keypoints": k, "force_num_keypoints": True,
+                            "chunk": batch}).eval().to(dev)
+    mat = lightglue_pretrained.LightGlue({"features": "disk", "weights": "synthetic", "filter_threshold": 0.1}).eval().to(dev)
+    g0, g1 = synthetic.synthetic_pairs(pairs, H, W, seed=77, device=dev)
+    rgb0 = torch.cat([g0 * 0.8, g0, g0 * 0.9], 1).contiguous()
+    rgb1 = torch.cat([g1 * 0.8, g1, g1 * 0.9], 1).contiguous()
+    size = torch.tensor([[float(W), float(H)]] * pairs, device=dev)
+
+    def timed(fn, n):
+        for _ in range(2):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            out = fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / n, out
+
+    def pair_step():
+        p0, p1 = ext({"image": rgb0}), ext({"image": rgb1})
+        return mat({"keypoints0": p0["keypoints"], "keypoints1": p1["keypoints"], "descriptors0": p0["descriptors"],
+                    "descriptors1": p1["descriptors"], "view0": {"image_size": size}, "view1": {"image_size": size}})
+
+    with torch.no_grad():
+        t_net, _ = timed(lambda: ext.model.dense_nhwc(rgb0[:batch]), iters)
+        t_ext, _ = timed(lambda: ext({"image": rgb0[:batch]}), iters)
+        t_pair, pred = timed(pair_step, max(iters // 2, 2))
+    layers = [(3, 16, 0), (16, 32, 1), (32, 64, 2), (64, 64, 3), (64, 64, 4), (128, 64, 3), (128, 64, 2), (96, 64, 1), (80, 129, 0)]
+    flops = sum(2 * 25 * ci * co * (H >> lv) * (W >> lv) for ci, co, lv in layers)
+    return {"disk_unet_ms_per_image": round(t_net * 1e3 / batch, 3),
+            "disk_unet_algorithmic_tflops": round(flops * batch / t_net / 1e12, 1),
+            "disk_extractor_ms_per_image": round(t_ext * 1e3 / batch, 3),
+            "disk_lightglue128_pairs_per_s": round(pairs / t_pair, 1),
+            "mean_matches_per_pair": round(float((pred["matches0"] >= 0).sum()) / pairs, 1),
+            "sample": f"VGA RGB, {k} key points, extractor in chunks of {batch} images (disk_kornia.py:55-137); pairs/s = "
+                      f"{pairs} pairs per step: DISK on both views + LightGlue with input_dim 128; name-seeded weights; "
+                      "parity of the network unpinned (kornia absent offline: HIP vs the CPU restatement of its published source)"}
+
+
 def host_barrier_group(world):
     """A gloo group for the job's closing barrier (rank 0 spends about a minute on the CPU baseline after the timed region:
     the other ranks wait on the host instead of spinning in an RCCL kernel).  One node only (the bench contract), so the
@@ -412,7 +504,7 @@ def main():
     ap.add_argument("--no-experimental", action="store_true",
                     help="accepted for older scripts (the split-arithmetic leg was retired in round 4)")
     ap.add_argument("--no-batch1", action="store_true",
-                    help="skip the informational `batch1` leg (single-pair latency of the batch-1 evaluation regime)")
+                    help="skip the informational legs (`batch1` single-pair latency, `c3_regime`, `c4`, `config5`)")
     ap.add_argument("--conv-arithmetic", default=None, choices=[None, "fp32", "winograd"],
                     help="3x3 convolutions of the timed path: Winograd F(2x2,3x3) / F(4x4,3x3) stem on fp32 MFMA (default) "
                          "or the direct implicit GEMM on fp32 MFMA")
@@ -652,6 +744,13 @@ def main():
                 out["c3_regime"] = c3_regime(dev)
             except Exception as e:  # noqa: BLE001
                 out["c3_regime"] = {"pair_batch32": None, "error": repr(e)[:200]}
+        if args.workload == "c2" and not args.no_batch1 and world == 1:
+            for key, leg in (("c4", c4_shape), ("config5", config5)):
+                try:  # information only: the other BASELINE configs' shapes (never `value`)
+                    out[key] = leg(dev)
+                except Exception as e:  # noqa: BLE001
+                    out[key] = {"pairs_per_s": None, "error": repr(e)[:200]}
+                torch.cuda.empty_cache()
         if not args.no_cpu_baseline:
             # rank 0 only, after the timed region and the gather; at N > 1 the other ranks wait at the closing barrier
             out["cpu_baseline"] = cpu_baseline(args.cpu_pairs, args.cpu_iters)

@@ -91,6 +91,12 @@ class DiskUnet(nn.Module):
         self._packed = None
         return ret
 
+    def _load_from_state_dict(self, *args, **kwargs):
+        # a PARENT's load_state_dict (DISK, TwoViewPipeline) recurses through this hook, not through the override
+        # above: weights loaded that way must also drop the packed device copies of the previous ones
+        self._packed = None
+        return super()._load_from_state_dict(*args, **kwargs)
+
     def _apply(self, fn, *args, **kwargs):
         self._packed = None
         return super()._apply(fn, *args, **kwargs)

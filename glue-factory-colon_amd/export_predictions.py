@@ -39,7 +39,15 @@ def _to_device(data, device):
 def _replicate(model):
     """Independent copy of a model for another worker: own parameters, own workspaces; cached packed weights (raw
     device pointers into the original's tensors) are dropped so that the copy packs its own on first use."""
-    rep = copy.deepcopy(model)
+    # a model that has already run holds ctypes parameter structs in `_packed` (not copyable): set aside for the copy
+    stash = [(m, m._packed) for m in model.modules() if getattr(m, "_packed", None) is not None]
+    for m, _ in stash:
+        m._packed = None
+    try:
+        rep = copy.deepcopy(model)
+    finally:
+        for m, packed in stash:
+            m._packed = packed
     for m in rep.modules():
         if hasattr(m, "_packed"):
             m._packed = None
@@ -110,9 +118,13 @@ def _sharded(loader, rank, world):
           and hasattr(loader.dataset, "__len__") and hasattr(loader.dataset, "__getitem__")):
         from .sharding import round_robin_shard
         idx = list(round_robin_shard(len(loader.dataset), rank, world))
+        extra = {"timeout": loader.timeout, "generator": loader.generator}
+        if loader.num_workers > 0:  # only valid with worker processes
+            extra.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers,
+                         multiprocessing_context=loader.multiprocessing_context)
         sub = DataLoader(Subset(loader.dataset, idx), batch_size=1, shuffle=False, num_workers=loader.num_workers,
                          collate_fn=loader.collate_fn, pin_memory=loader.pin_memory,
-                         worker_init_fn=loader.worker_init_fn)
+                         worker_init_fn=loader.worker_init_fn, **extra)
         yield from zip(idx, sub)
     elif hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
         from .sharding import round_robin_shard
@@ -124,12 +136,38 @@ def _sharded(loader, rank, world):
                 yield i, item
 
 
-def _merge_parts(output_file, world):
-    """Rank 0: the per-rank part files -> one prediction file, records in loader order, first name wins."""
+def _gather_to_rank0(local, failed_here, rank, world, device):
+    """the ONE data collective of the sharded export -- every rank's records travel to rank 0 as one block
+    of bytes, padded to the largest block (the npz container inside keeps each pair's arrays with their own shapes
+    and dtypes: an HPatches pair is ~40 KB, 540 pairs ~22 MB over 8 ranks).  A one-integer all-gather in front of it
+    carries the block sizes and doubles as the failure flag (-1): a rank that failed must not leave the others
+    waiting in a collective.  Returns (entries on rank 0 / None elsewhere, any_rank_failed)."""
+    import io
+
+    import torch.distributed as dist
+    dev = device if dist.get_backend() == "nccl" else "cpu"
+    payload = b""
+    if not failed_here:
+        buf = io.BytesIO()
+        np.savez(buf, **{f"{idx}|{name}/{k}": v for idx, name, rec in local for k, v in rec.items()})
+        payload = buf.getvalue()
+    mine = torch.tensor([-1 if failed_here else len(payload)], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(sizes, mine)
+    sizes = [int(t.item()) for t in sizes]
+    if min(sizes) < 0:
+        return None, True
+    block = torch.zeros(max(max(sizes), 1), dtype=torch.uint8)
+    if payload:
+        block[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    block = block.to(dev)
+    out = [torch.empty_like(block) for _ in range(world)] if rank == 0 else None
+    dist.gather(block, out, dst=0)
+    if rank != 0:
+        return None, False
     entries = []
     for r in range(world):
-        part = Path(str(output_file) + f".part{r}")
-        with np.load(part, allow_pickle=False) as z:
+        with np.load(io.BytesIO(out[r][:sizes[r]].cpu().numpy().tobytes()), allow_pickle=False) as z:
             recs = {}
             for full in z.files:
                 head, key = full.rsplit("/", 1)
@@ -137,12 +175,7 @@ def _merge_parts(output_file, world):
         for head, rec in recs.items():
             idx, name = head.split("|", 1)
             entries.append((int(idx), name, rec))
-        part.unlink()
-    records = {}
-    for _, name, rec in sorted(entries, key=lambda e: e[0]):
-        if name not in records:
-            records[name] = rec
-    _write(Path(output_file), records)
+    return entries, False
 
 
 @torch.no_grad()
@@ -150,9 +183,10 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
                        workers=1, rank=None, world=None, pair_batch=1):
     """pair_batch: number of consecutive pairs processed by one `model.forward_pairs` call (module docstring).
     rank / world (default: the torch.distributed process group, if one is initialised): the pair list is shared
-    out round-robin over the ranks (one process per GPU, no data-path collective); every rank writes a part file
-    next to `output_file`, and after one barrier rank 0 merges them into the single prediction file the evaluation
-    reads (records in loader order, as the single-process loop writes them).  All ranks return `output_file`."""
+    out round-robin over the ranks (one process per GPU, no data-path collective); at the end ONE gather brings every
+    rank's records to rank 0 (RCCL over xGMI: one direct peer write per rank), which writes the single
+    prediction file the evaluation reads (records in loader order, as the single-process loop writes them) -- no
+    part files, no shared file system between the ranks.  All ranks return `output_file`."""
     assert keys == "*" or isinstance(keys, (tuple, list))
     optional_keys = list(optional_keys)
     output_file = Path(output_file)
@@ -165,38 +199,32 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
     device = "cuda" if torch.cuda.is_available() else "cpu"
     model = model.to(device).eval()
     if world > 1:
-        inner = Path(str(output_file) + f".part{rank}")
-        # A rank that fails must not leave the others waiting at a barrier for ever: every rank reports a status
-        # flag through ONE all-reduce (the synchronisation point), and all of them raise together if any failed.
         failure = None
+        local = []
         try:
-            local = []
             _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half,
                          workers, local, pair_batch)
-            flat = {f"{idx}|{name}/{k}": v for idx, name, rec in local for k, v in rec.items()}
-            with open(inner, "wb") as fh:
-                np.savez(fh, **flat)
         except Exception as e:  # noqa: BLE001 -- re-raised below, after the other ranks have been told
             failure = e
-        if _any_rank_failed(failure is not None, device):
-            inner.unlink(missing_ok=True)  # no stale part files after a failed run
+        entries, failed = _gather_to_rank0(local, failure is not None, rank, world, device)
+        if failed:
             if failure is not None:
                 raise failure
-            raise RuntimeError("export_predictions: another rank failed; nothing was merged")
+            raise RuntimeError("export_predictions: another rank failed; nothing was written")
         try:
-            if rank == 0:
-                _merge_parts(output_file, world)
+            if rank == 0:  # records in loader order, first name wins (as the single-process loop)
+                records = {}
+                for _, name, rec in sorted(entries, key=lambda e: e[0]):
+                    if name not in records:
+                        records[name] = rec
+                _write(output_file, records)
         except Exception as e:  # noqa: BLE001
             failure = e
-        finally:
-            failed = _any_rank_failed(failure is not None, device)
-            if failed:
-                for r in range(world) if rank == 0 else ():
-                    Path(str(output_file) + f".part{r}").unlink(missing_ok=True)
+        failed = _any_rank_failed(failure is not None, device)  # closing barrier: the file exists when any rank returns
         if failure is not None:
             raise failure
         if failed:
-            raise RuntimeError("export_predictions: merging the part files failed on rank 0")
+            raise RuntimeError("export_predictions: writing the prediction file failed on rank 0")
         return output_file
     local = []
     _export_loop(enumerate(loader), model, device, keys, optional_keys, callback_fn, as_half, workers, local,

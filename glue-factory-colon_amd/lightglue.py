@@ -12,6 +12,7 @@ sub-modules are parameter containers only; the forward pass is one call into lib
 """
 import ctypes
 import os
+import sys
 import threading
 from pathlib import Path
 
@@ -229,7 +230,13 @@ class LightGlue(nn.Module):
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     run()
             e["graph"] = graph
-        except Exception:  # noqa: BLE001 -- e.g. another thread is using the device: this shape stays eager
+        except nat.NativeError:
+            raise  # an error status of gfc_lg_forward_packed is a real failure, never a reason to fall back
+        except RuntimeError as exc:  # the capture itself was refused (e.g. another thread is using the device)
+            if not getattr(LightGlue, "_graph_fallback_logged", False):
+                LightGlue._graph_fallback_logged = True
+                print(f"glue_factory_colon_amd.lightglue: HIP graph capture refused ({exc}); problems of shape "
+                      f"{key[:3]} run with eager launches", file=sys.stderr)
             e = {"graph": None}
         self._graphs[key] = e
         return e

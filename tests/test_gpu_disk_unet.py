@@ -197,3 +197,20 @@ def test_config5_disk_plus_lightglue_pipeline_vs_oracle():
     assert (pred["matching_scores0"].cpu() - ref["matching_scores0"]).abs().max() < 1e-4
     from parity_utils import record
     record("config5_pipeline", matches=int((ref["matches0"] >= 0).sum()), keypoints=int(pred["keypoints0"].shape[1]))
+
+
+def test_weights_loaded_through_the_wrapper_replace_the_packed_ones():
+    """A forward packs device copies of the weights; weights loaded afterwards through a PARENT module's
+    load_state_dict (nn.Module recursion, not DiskUnet's own override) must be the ones the next forward uses."""
+    m = disk_kornia.DISK({"max_num_keypoints": 128, "weights": "synthetic"}).eval().to(DEV)
+    img = torch.rand((1, 3, 64, 96), generator=torch.Generator().manual_seed(3)).to(DEV)
+    a = m({"image": img})["keypoint_scores"].clone()
+    assert m.model._packed is not None
+    other = {"model." + k: v for k, v in weights.disk_state_dict(7).items()}
+    missing = m.load_state_dict(other, strict=False)
+    assert not missing.unexpected_keys
+    assert m.model._packed is None
+    b = m({"image": img})["keypoint_scores"]
+    assert a.shape != b.shape or not torch.equal(a, b)
+    m.load_state_dict({"model." + k: v for k, v in weights.disk_state_dict(0).items()}, strict=False)
+    assert torch.equal(m({"image": img})["keypoint_scores"], a)

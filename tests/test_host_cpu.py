@@ -267,8 +267,8 @@ def test_bench_spawns_its_own_ranks_without_a_launcher():
 
 
 def test_export_predictions_sharded_world2_gloo(tmp_path):
-    """HPatches-style export shared out over 2 ranks (round-robin over the pair list, one part file per rank, one
-    barrier, rank 0 merges): the merged file equals the single-process export -- same record names in loader order,
+    """HPatches-style export shared out over 2 ranks (round-robin over the pair list, ONE gather of the ranks' record
+    blocks to rank 0, which writes the file -- SURVEY.md 8e; no part files): the file equals the single-process export -- same record names in loader order,
     same arrays, key points un-scaled by 1 / scales (reference utils/export_predictions.py:36-85).  Fake model on CPU."""
     script = tmp_path / "w.py"
     script.write_text(
@@ -312,6 +312,40 @@ def test_export_predictions_sharded_world2_gloo(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0 and "SHARDED_EXPORT_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_export_predictions_sharded_failure_does_not_hang(tmp_path):
+    """One rank's model raises: every rank leaves export_predictions with an exception (the failing one with its own, the
+    other with "another rank failed") instead of waiting in the gather, and no prediction file is written."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from glue_factory_colon_amd import sharding\n"
+        "from glue_factory_colon_amd.export_predictions import export_predictions\n"
+        "rank, world, _ = sharding.init_from_env('gloo')\n"
+        "class Fake(torch.nn.Module):\n"
+        "    def forward(self, data):\n"
+        "        if rank == 1:\n"
+        "            raise ValueError('boom on rank 1')\n"
+        "        return {'keypoints0': data['view0']['x']}\n"
+        "items = [{'name': [f's/{i}.ppm'], 'view0': {'x': torch.ones(1, 3, 2), 'scales': torch.ones(1, 2)}} for i in range(4)]\n"
+        "try:\n"
+        "    export_predictions(items, Fake(), sys.argv[1] + '/p.npz')\n"
+        "    print('NO_EXCEPTION', rank)\n"
+        "except ValueError as e:\n"
+        "    print('OWN_FAILURE', rank, e)\n"
+        "except RuntimeError as e:\n"
+        "    print('TOLD', rank, e)\n"
+        "assert not os.path.exists(sys.argv[1] + '/p.npz')\n"
+        "torch.distributed.barrier()\n")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "OWN_FAILURE 1 boom on rank 1" in r.stdout and "TOLD 0" in r.stdout and "another rank failed" in r.stdout
 
 
 def test_hdf5_prediction_file_without_h5py(tmp_path):
