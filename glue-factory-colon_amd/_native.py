@@ -66,6 +66,8 @@ SIGNATURES = {
     "gfc_attention_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_linear_layernorm_gelu": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "gfc_ffn_fused": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "gfc_layernorm_gelu": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfc_sp_workspace_bytes": (c_size_t, [c_int] * 4),
     "gfc_sp_dense": (c_int, [POINTER(SpParams), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,

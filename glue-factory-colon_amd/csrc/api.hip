@@ -342,6 +342,15 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
     GFC_TRY(lin(a0, D, D, a1, D, D, w0, 512, b0, nullptr, nullptr, nullptr, 0, hbuf, 512, 512));
     return gfc_layernorm_gelu(hbuf, 512, R, 512, ln_g, ln_b, st);
   };
+  // the whole FFN (ffn[0] -> LayerNorm -> GELU -> ffn[3] + residual) in one kernel where the row-owning kernel runs
+  // (knob: GFC_FFN_MLP = 0 keeps ffn[3] as a GEMM of its own; results are bit-identical either way)
+  const bool ffn_mlp = ffn_fused && gfc_knobs().ffn_fused != 1 && gfc_knobs().ffn_mlp != 0;
+  auto ffn = [&](const float* a0, const float* a1, const float* w0, const float* b0, const float* ln_g, const float* ln_b,
+                 const float* w3, const float* b3, const float* resid) -> int {
+    if (ffn_mlp) return gfc_ffn_fused(a0, D, D, a1, D, D, w0, 512, b0, ln_g, ln_b, w3, 512, b3, resid, x, D, R, st);
+    GFC_TRY(ffn01(a0, a1, w0, b0, ln_g, ln_b));
+    return lin(hbuf, 512, 512, nullptr, 0, 0, w3, 512, b3, resid, nullptr, nullptr, 0, x, D, D);
+  };
   const float* xs = x_in ? x_in : x;  // what the self block reads
   {
 
@@ -359,8 +368,7 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1s = msg;
     }
-    GFC_TRY(ffn01(xs, a1s, p->s_ffn0_w[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l]));
-    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->s_ffn3_w[l], 512, p->s_ffn3_b[l], xs, nullptr, nullptr, 0, x, D, D));
+    GFC_TRY(ffn(xs, a1s, p->s_ffn0_w[l], p->s_ffn0_b[l], p->s_ln_g[l], p->s_ln_b[l], p->s_ffn3_w[l], p->s_ffn3_b[l], xs));
     // ---- cross block (lightglue.py:193-222) ----
     GFC_TRY(lin(x, D, D, nullptr, 0, 0, p->c_qkv_w[l], D, p->c_qkv_b[l], nullptr, nullptr, nullptr, 0, qkv, 512, 512));
     GFC_TRY(attn(qkv, 512, qkv, 512, qkv + 256, 512, cross_p));
@@ -370,8 +378,7 @@ static int lg_layer_impl(const gfc_lg_params* p, int l, float* x, const float* c
                          nullptr, nullptr, 0, msg, D, R, D, st));
       a1c = msg;
     }
-    GFC_TRY(ffn01(x, a1c, p->c_ffn0_w[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l]));
-    GFC_TRY(lin(hbuf, 512, 512, nullptr, 0, 0, p->c_ffn3_w[l], 512, p->c_ffn3_b[l], x, nullptr, nullptr, 0, x, D, D));
+    GFC_TRY(ffn(x, a1c, p->c_ffn0_w[l], p->c_ffn0_b[l], p->c_ln_g[l], p->c_ln_b[l], p->c_ffn3_w[l], p->c_ffn3_b[l], x));
     }
   return GFC_OK;
 }

@@ -511,9 +511,22 @@ __device__ __forceinline__ float halfwave_transpose_sum32(const float (&x)[32], 
 //   WM = 1:  64 x 512 tile, 4 waves, K tile 8,   54 KB LDS: two workgroups per CU that run out of phase, so the
 //            VALU-heavy epilogue (LayerNorm + erf, ~50 instructions per element) and the store drain of one
 //            overlap the MFMAs of the other.
-template <int WM>
+//
+// MLP = true (WM = 2 only; round 4): the WHOLE LightGlue FFN in the kernel -- Linear(512,512) -> LayerNorm -> GELU ->
+// Linear(512,256) + residual (lightglue.py:143-148,162-164).  The activated 128 x 512 hidden tile stays in the
+// accumulator registers; it is handed to the second GEMM through LDS in four 128-column chunks (the column group wn = c
+// owns chunk c), which the eight waves consume as the A operand of Y[128,256] += H[:, chunk] . W3[:, chunk]^T with W3
+// staged in 16-deep K tiles exactly like W0 in the first loop.  Second-GEMM wave tile: wm -> 64 rows, wn -> 64 output
+// columns (2 x 2 MFMA tiles, 64 more accumulator registers).  Same k order per output element as gemm_nt_kernel
+// (ascending 8-deep groups, k = 4h + s inside a group), same epilogue association (residual + (acc + bias)): the
+// results are bit-identical to the two-kernel path.  The [M,512] hidden activation never exists in HBM.
+#define FF_HLD 148  // hidden-chunk row stride in floats (= 20 mod 64: the conflict-free ds_read_b128 pattern of the K-tile rows)
+template <int WM, bool MLP = false>
 __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmArgs g, const float* __restrict__ gamma,
-                                                                           const float* __restrict__ beta) {
+                                                                           const float* __restrict__ beta,
+                                                                           const float* __restrict__ W3, int ldw3,
+                                                                           const float* __restrict__ b3) {
+  static_assert(!MLP || WM == 2, "the fused MLP is built for the 128-row tile");
   constexpr int BM = 64 * WM, BK = WM == 2 ? 16 : 8, LD = BK + 4, C4 = BK / 4;
   constexpr int TILE = (BM + GW_BN) * LD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -615,6 +628,25 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
 #undef GW_LOAD
 #undef GW_STORE
   GEMM_STAMP(2);
+  // fused MLP: W3's K tiles are staged through LDS behind the hidden chunk; tile 0 is requested now and lands under
+  // the LayerNorm / GELU epilogue (all reads of the first loop's buffers are behind its closing barrier)
+  constexpr int W3T = 256 * LD;                         // one staged W3 K tile: 256 output columns x 16 k
+  float* const Hs = smem;                               // [128][FF_HLD]
+  float* const Ws = smem + 128 * FF_HLD;                // 2 x [256][LD]
+  const float* w3p0 = MLP ? W3 + (size_t)s_r0 * ldw3 + s_c4 : nullptr;
+  const float* w3p1 = MLP ? w3p0 + (size_t)128 * ldw3 : nullptr;
+#define FF_LOAD(T_)                                                   \
+  do {                                                                \
+    wreg0 = *reinterpret_cast<const float4*>(w3p0 + (T_) * 16);       \
+    wreg1 = *reinterpret_cast<const float4*>(w3p1 + (T_) * 16);       \
+  } while (0)
+#define FF_STORE(buf_)                                                \
+  do {                                                                \
+    float* bs_ = Ws + (buf_) * W3T + s_r0 * LD + s_c4;                \
+    *reinterpret_cast<float4*>(bs_) = wreg0;                          \
+    *reinterpret_cast<float4*>(bs_ + 128 * LD) = wreg1;               \
+  } while (0)
+  if constexpr (MLP) FF_LOAD(0);
 
   // ---- epilogue: + bias, LayerNorm over the 512 columns of each row, GELU, store ----
   float* red = smem;          // [4][BM] per-column-wave row partials
@@ -690,7 +722,11 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
       for (int j = 0; j < 4; ++j) {
         const int r = 4 * gq + j;
         const int row = m0 + wm * 64 + mt * 32 + acc_row(r, h);
-        if (full_rows || row < g.M) {  // full_rows: workgroup-uniform, no per-row predicate blocks
+        if constexpr (MLP) {  // the activated value replaces the pre-activation in its accumulator register
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[mt][nt][r] = gfc_gelu((acc[mt][nt][r] - mu[mt][r]) * rs[j] * ga[nt] + be[nt]);
+        } else if (full_rows || row < g.M) {  // full_rows: workgroup-uniform, no per-row predicate blocks
           float* yp = g.Y + (size_t)row * g.ldy + wn * 128 + l31;
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt) {
@@ -711,6 +747,92 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
   GEMM_STAMP(4);
 #endif
+  if constexpr (MLP) {
+    // ---- second GEMM: Y[128,256] = H[128,512] . W3[256,512]^T, K walked in four chunks of 128 hidden columns ----
+    f32x16 acc2[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[mt][nt][r] = 0.f;
+    const int a_off3 = (wm * 64 + l31) * FF_HLD + 4 * h;
+    const int b_off3 = (wn * 64 + l31) * LD + 4 * h;
+    FF_STORE(0);  // tile 0 (requested before the epilogue); `stat` / `red` live below Ws and were last read above
+    FF_LOAD(1);
+    __syncthreads();  // every wave is past its last read of `stat` (which aliases the hidden chunk)
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      if (wn == c) {  // wave-uniform: this column group's 128 hidden columns -> LDS (row = accumulator row, column on the lane)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              Hs[(wm * 64 + mt * 32 + acc_row(r, h)) * FF_HLD + nt * 32 + l31] = acc[mt][nt][r];
+      }
+      __syncthreads();
+#pragma unroll 1
+      for (int t = 0; t < 8; ++t) {
+        const int T = c * 8 + t;
+        if (T + 1 < 32) {
+          FF_STORE((T + 1) & 1);
+          if (T + 2 < 32) FF_LOAD(T + 2);
+        }
+        const float* ap = Hs + a_off3 + 16 * t;
+        const float* bp = Ws + (T & 1) * W3T + b_off3;
+#pragma unroll
+        for (int gk = 0; gk < 2; ++gk) {
+          float4 af[2], bf[2];
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * FF_HLD + 8 * gk);
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) bf[nt] = *reinterpret_cast<const float4*>(bp + nt * 32 * LD + 8 * gk);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              acc2[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc2[mt][nt]);
+              acc2[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc2[mt][nt]);
+              acc2[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc2[mt][nt]);
+              acc2[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc2[mt][nt]);
+            }
+        }
+        __syncthreads();
+      }
+    }
+    // ---- epilogue: Y = residual + (acc + b3), straight from the accumulator layout (128-byte row segments) ----
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = wn * 64 + nt * 32 + l31;
+      float bi3 = b3 ? b3[col] : 0.f;
+      asm volatile("" : "+v"(bi3));
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int row0 = m0 + wm * 64 + mt * 32 + 4 * h;
+        const size_t o0 = (size_t)row0 * g.ldy + col;
+        float rv[16];
+        if (full_rows) {  // workgroup-uniform: all residual loads first, then the stores back to back
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rv[r] = g.residual ? g.residual[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldy] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) g.Y[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * g.ldy] = rv[r] + (acc2[mt][nt][r] + bi3);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            if (row < g.M) {
+              const size_t o = (size_t)row * g.ldy + col;
+              g.Y[o] = (g.residual ? g.residual[o] : 0.f) + (acc2[mt][nt][r] + bi3);
+            }
+          }
+        }
+      }
+    }
+  }
+#undef FF_LOAD
+#undef FF_STORE
 }
 
 template <int WM>
@@ -723,7 +845,32 @@ static int launch_rows512(const GemmArgs& g, const float* gamma, const float* be
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
   gd.stamps = g_diag_stamps;
 #endif
-  hipLaunchKernelGGL(gemm_rows512_ln_gelu_kernel<WM>, dim3((g.M + BM - 1) / BM), dim3(256 * WM), lds, st, gd, gamma, beta);
+  hipLaunchKernelGGL(gemm_rows512_ln_gelu_kernel<WM>, dim3((g.M + BM - 1) / BM), dim3(256 * WM), lds, st, gd, gamma, beta,
+                     (const float*)nullptr, 0, (const float*)nullptr);
+  GFC_LAUNCH_CHECK();
+  return GFC_OK;
+}
+
+extern "C" int gfc_ffn_fused(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W0,
+                             int ldw0, const float* b0, const float* gamma, const float* beta, const float* W3, int ldw3,
+                             const float* b3, const float* residual, float* Y, int ldy, int M, void* stream) {
+  if (!A0 || !W0 || !gamma || !beta || !W3 || !Y || M <= 0 || K0 <= 0 || K0 % GBK || K1 % GBK || K1 < 0)
+    return GFC_ERR_INVALID;
+  if ((K1 > 0) != (A1 != nullptr)) return GFC_ERR_INVALID;
+  if (lda0 % 4 || (A1 && lda1 % 4) || ldw0 % 4 || ldw3 % 4 || ldw3 < GW_BN || ldy < 256) return GFC_ERR_INVALID;
+  GemmArgs g = {};
+  g.A0 = A0; g.A1 = A1; g.W = W0; g.bias = b0; g.residual = residual; g.Y = Y;
+  g.lda0 = lda0; g.lda1 = lda1; g.ldw = ldw0; g.ldy = ldy;
+  g.K0 = K0; g.K1 = K1; g.M = M; g.N = GW_BN; g.alpha = 1.f;
+  constexpr size_t k1 = (size_t)2 * (128 + GW_BN) * 20, k2 = (size_t)128 * FF_HLD + (size_t)2 * 256 * 20;
+  constexpr size_t lds = (k1 > k2 ? k1 : k2) * sizeof(float);
+  static std::atomic<unsigned long long> lds_ok{0};
+  gfc_allow_dynamic_lds((const void*)gemm_rows512_ln_gelu_kernel<2, true>, lds, lds_ok);
+#if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
+  g.stamps = g_diag_stamps;
+#endif
+  hipLaunchKernelGGL((gemm_rows512_ln_gelu_kernel<2, true>), dim3((M + 127) / 128), dim3(512), lds, (hipStream_t)stream, g,
+                     gamma, beta, W3, ldw3, b3);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }

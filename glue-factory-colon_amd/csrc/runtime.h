@@ -18,6 +18,7 @@ struct GfcKnobs {
   int conv_kc;       // GFC_CONV_KC: 0 = automatic
   int conv_persist;  // GFC_CONV_PERSIST: -1 = automatic
   int ffn_fused;     // GFC_FFN_FUSED: -1 = automatic, 0 = GEMM + layernorm_gelu pass, 1 = row-owning fused GEMM
+  int ffn_mlp;       // GFC_FFN_MLP: -1 = automatic, 0 = ffn[3] as a GEMM of its own, 1 = whole FFN + residual in one kernel
   int assign_mode;   // GFC_ASSIGN_MODE: 0 = automatic, 1 = five-pass tail, 2 = two-pass tail
   int gemm_epi;      // GFC_GEMM_EPI: 0 = automatic, 1 = float4 stores through the LDS transpose for every epilogue, 2 = direct
   int gemm_stagger;  // GFC_GEMM_STAGGER: start skew of the first-round GEMM workgroups in units of 8128 cycles per wave slot

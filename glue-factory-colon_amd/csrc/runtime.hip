@@ -21,6 +21,7 @@ const GfcKnobs& gfc_knobs() {
     g_knobs.conv_kc = env_int("GFC_CONV_KC", 0);
     g_knobs.conv_persist = env_int("GFC_CONV_PERSIST", -1);
     g_knobs.ffn_fused = env_int("GFC_FFN_FUSED", -1);
+    g_knobs.ffn_mlp = env_int("GFC_FFN_MLP", -1);
     g_knobs.assign_mode = env_int("GFC_ASSIGN_MODE", 0);
     g_knobs.gemm_epi = env_int("GFC_GEMM_EPI", 0);
     g_knobs.gemm_stagger = env_int("GFC_GEMM_STAGGER", 0);

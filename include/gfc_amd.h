@@ -126,6 +126,17 @@ size_t gfc_attention_workspace_bytes(int n_problems, int max_nq, int heads);
 int gfc_layernorm_gelu(float* x, int ld, int rows, int width, const float* gamma, const float* beta,
                        void* stream);
 
+/* The WHOLE LightGlue FFN with its residual in one kernel (lightglue.py:143-148, called at :162-164,219-222):
+ *   Y[M,256] = residual + ( GELU_erf( LayerNorm_512( [A0 | A1] * W0[512,K0+K1]^T + b0 ; gamma, beta, eps 1e-5 ) )
+ *                           * W3[256,512]^T + b3 ).
+ * Row-owning 128-row workgroup tiles: the row statistics, the [M,512] pre-activation AND the activated hidden tile stay
+ * on chip (the hidden tile goes from the first GEMM's accumulators through LDS into the second GEMM).  residual
+ * (nullable) and Y share the row stride ldy and may alias (in-place residual update); b3 nullable.  Bit-identical to
+ * gfc_linear_layernorm_gelu followed by gfc_linear(..., residual). */
+int gfc_ffn_fused(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* W0, int ldw0,
+                  const float* b0, const float* gamma, const float* beta, const float* W3, int ldw3, const float* b3,
+                  const float* residual, float* Y, int ldy, int M, void* stream);
+
 /* The first two stages of the LightGlue FFN in one kernel (lightglue.py:143-148, called at :164,221-222):
  *   Y[M,512] = GELU_erf( LayerNorm_512( [A0 | A1] * W[512,K0+K1]^T + bias ; gamma, beta, eps 1e-5 ) ).
  * Row-owning workgroup tiles (128 rows x all 512 columns): the row statistics stay on chip and the

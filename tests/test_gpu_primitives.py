@@ -525,6 +525,93 @@ def test_linear_layernorm_gelu_fused(m):
                                          nat.ptr(D(gamma)), nat.ptr(D(beta)), nat.ptr(y), 256, m, 256, st()) == 3
 
 
+@pytest.mark.parametrize("m", [65536, 16384 + 77, 100])
+def test_ffn_fused_whole_mlp(m):
+    """gfc_ffn_fused: the whole LightGlue FFN with its residual in ONE kernel -- Linear(512,512) -> LayerNorm -> GELU ->
+    Linear(512,256), + x (lightglue.py:143-148,162-164) -- against float64 torch, bit-identical to the two-kernel path
+    (gfc_linear_layernorm_gelu, then gfc_linear with the residual epilogue), in place (Y = residual = A0) as the cross
+    block uses it, and row-batch invariant (a row's result does not depend on which other rows share its launch)."""
+    lib = nat.lib()
+    g = gen(m + 1)
+    x, msg = torch.randn((m, 256), generator=g), torch.randn((m, 256), generator=g) * 2 + 0.3
+    w0 = torch.randn((512, 512), generator=g) / 512 ** 0.5
+    b0 = torch.randn((512,), generator=g)
+    gamma, beta = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g) * 0.2
+    w3 = torch.randn((256, 512), generator=g) / 512 ** 0.5
+    b3 = torch.randn((256,), generator=g)
+    dx, dmsg, dw0, db0, dga, dbe, dw3, db3 = (D(t) for t in (x, msg, w0, b0, gamma, beta, w3, b3))
+
+    def fused(a0, resid, y, rows=m, off=0):
+        o = off * 256 * 4
+        nat.check(lib.gfc_ffn_fused(nat.c_void_p(a0.data_ptr() + o), 256, 256, nat.c_void_p(dmsg.data_ptr() + o), 256, 256,
+                                    nat.ptr(dw0), 512, nat.ptr(db0), nat.ptr(dga), nat.ptr(dbe), nat.ptr(dw3), 512,
+                                    nat.ptr(db3), None if resid is None else nat.c_void_p(resid.data_ptr() + o),
+                                    nat.c_void_p(y.data_ptr() + o), 256, rows, st()), "gfc_ffn_fused")
+
+    y = torch.full((m, 256), float("nan"), device=DEV)
+    fused(dx, dx, y)
+    torch.cuda.synchronize()
+    ref = _ref64(lambda a, c, ww, bb, ga, be, w3_, b3_: a + F.linear(
+        F.gelu(F.layer_norm(F.linear(torch.cat([a, c], 1), ww, bb), (512,), ga, be, 1e-5)), w3_, b3_),
+        x, msg, w0, b0, gamma, beta, w3, b3)
+    assert maxerr(y, ref) < 3e-5
+    # the two-kernel path: bit-identical
+    hb = torch.empty((m, 512), device=DEV)
+    nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(dx), 256, 256, nat.ptr(dmsg), 256, 256, nat.ptr(dw0), 512, nat.ptr(db0),
+                                            nat.ptr(dga), nat.ptr(dbe), nat.ptr(hb), 512, m, 512, st()), "ln_gelu")
+    y2 = torch.empty((m, 256), device=DEV)
+    nat.check(lib.gfc_linear(nat.ptr(hb), 512, 512, None, 0, 0, nat.ptr(dw3), 512, nat.ptr(db3), None, None, 1.0,
+                             nat.ptr(dx), None, None, 0, nat.ptr(y2), 256, m, 256, st()), "ffn3")
+    assert torch.equal(y, y2)
+    # in place: Y = residual = A0 (the cross block's call)
+    xin = dx.clone()
+    fused(xin, xin, xin)
+    assert torch.equal(xin, y)
+    # no residual / rows of a launch are independent: a sub-range of rows alone gives the same rows
+    y3 = torch.empty((m, 256), device=DEV)
+    fused(dx, None, y3)
+    assert maxerr(y3 + dx, y) < 1e-5
+    if m > 300:
+        sub = torch.full((m, 256), float("nan"), device=DEV)
+        fused(dx, dx, sub, rows=200, off=37)
+        torch.cuda.synchronize()
+        assert torch.equal(sub[37:237], y[37:237]) and torch.isnan(sub[237:]).all() and torch.isnan(sub[:37]).all()
+    assert lib.gfc_ffn_fused(nat.ptr(dx), 256, 256, None, 0, 0, nat.ptr(dw0), 512, nat.ptr(db0), nat.ptr(dga), nat.ptr(dbe),
+                             nat.ptr(dw3), 256, nat.ptr(db3), None, nat.ptr(y3), 256, m, st()) == 1  # ldw3 < 512
+
+
+def test_ffn_mlp_knob_off_gives_identical_matcher_outputs(golden=None):
+    """GFC_FFN_MLP=0 (ffn[3] as a GEMM of its own) against the default (whole FFN in one kernel) on the batch-32 matcher:
+    every output tensor bit-identical (child process: the knob is read once per process)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import sys, torch, hashlib\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from glue_factory_colon_amd import lightglue\n"
+        "g = torch.Generator().manual_seed(5)\n"
+        "b, k = 16, 1024\n"
+        "kp0, kp1 = torch.rand((b, k, 2), generator=g) * 600, torch.rand((b, k, 2), generator=g) * 600\n"
+        "d0 = torch.nn.functional.normalize(torch.randn((b, k, 256), generator=g), dim=-1)\n"
+        "d1 = torch.nn.functional.normalize(d0 + 0.3 * torch.randn((b, k, 256), generator=g), dim=-1)\n"
+        "size = torch.tensor([[640.0, 480.0]] * b).cuda()\n"
+        "m = lightglue.LightGlue({'weights': 'synthetic', 'filter_threshold': 0.1}).eval().cuda()\n"
+        "p = m({'keypoints0': kp0.cuda(), 'keypoints1': kp1.cuda(), 'descriptors0': d0.cuda(), 'descriptors1': d1.cuda(),\n"
+        "       'view0': {'image_size': size}, 'view1': {'image_size': size}})\n"
+        "h = hashlib.sha256()\n"
+        "for key in sorted(p): h.update(p[key].cpu().numpy().tobytes())\n"
+        "print('DIGEST', h.hexdigest(), int((p['matches0'] >= 0).sum()))\n")
+    outs = []
+    for knob in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, GFC_FFN_MLP=knob))
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append([ln for ln in r.stdout.splitlines() if ln.startswith("DIGEST")][0])
+    assert outs[0] == outs[1], outs
+    assert int(outs[0].split()[-1]) > 1000
+
+
 def test_ffn_fused_variants_via_knob():
     """GFC_FFN_FUSED=1 (64-row tiles, two workgroups per CU) passes the same test as the default 128-row tile."""
     import subprocess

@@ -85,6 +85,28 @@ def bench_ffn_fused():
 
     report("ffn0 + layernorm_gelu (2 kernels)", timeit(two), 2.0 * R * 512 * 512)
     report("ffn0+LN+GELU fused (rows512 kernel)", timeit(one), 2.0 * R * 512 * 512)
+    # the whole FFN: ffn0 -> LN -> GELU -> ffn3 + residual, two kernels vs gfc_ffn_fused (round 4)
+    w3 = torch.randn((256, 512), device=DEV) / 22
+    b3 = torch.randn((256,), device=DEV)
+    out = torch.empty((R, 256), device=DEV)
+
+    def ffn3():
+        nat.check(lib.gfc_linear(nat.ptr(y), 512, 512, None, 0, 0, nat.ptr(w3), 512, nat.ptr(b3), None, None, 1.0,
+                                 nat.ptr(x), None, None, 0, nat.ptr(out), 256, R, 256, st), "ffn3")
+
+    def pair():
+        one()
+        ffn3()
+
+    def mlp():
+        nat.check(lib.gfc_ffn_fused(nat.ptr(x), 256, 256, nat.ptr(msg), 256, 256, nat.ptr(w), 512, nat.ptr(b), nat.ptr(ga),
+                                    nat.ptr(be), nat.ptr(w3), 512, nat.ptr(b3), nat.ptr(x), nat.ptr(out), 256, R, st), "mlp")
+
+    flops = 2.0 * R * 512 * 512 + 2.0 * R * 512 * 256
+    for _ in range(2):  # alternated: same box, same thermal state
+        report("ffn3 N=256 K=512 residual (gemm_nt)", timeit(ffn3), 2.0 * R * 512 * 256)
+        report("FFN as two kernels (rows512 + ffn3)", timeit(pair), flops)
+        report("FFN whole MLP in one kernel (gfc_ffn_fused)", timeit(mlp), flops)
 
 
 def bench_gemm_sweep():
