@@ -53,7 +53,7 @@ PAIR_FLOPS_EXECUTED = 2 * (2504 * 4096 * 600 + 4.0 / 9.0 * 28.31e9 + 0.79e9) + 7
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-PMC_SUMMARIES = ("r03_pmc_summary.json", "r02_pmc_summary.json")  # newest first
+PMC_SUMMARIES = ("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json")  # newest first
 
 
 def pmc_traffic_bytes(kernel_prefix):

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
     stat[BM + tid] = 1.f / sqrtf(var + 1e-5f);
   }
   __syncthreads();
-  GEMM_STAMP(3);  // statistics done
+  if constexpr (!MLP) GEMM_STAMP(3);  // statistics done
   const bool full_rows = m0 + BM <= g.M;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
@@ -745,7 +745,8 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
     }
   }
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
-  GEMM_STAMP(4);
+  if constexpr (MLP) GEMM_STAMP(3);  // MLP stamps: 3 = LayerNorm + GELU done, 4 = second K loop done, 7 = stores issued
+  else GEMM_STAMP(4);
 #endif
   if constexpr (MLP) {
     // ---- second GEMM: Y[128,256] = H[128,512] . W3[256,512]^T, K walked in four chunks of 128 hidden columns ----
@@ -802,6 +803,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
         __syncthreads();
       }
     }
+    GEMM_STAMP(4);
     // ---- epilogue: Y = residual + (acc + b3), straight from the accumulator layout (128-byte row segments) ----
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -830,6 +832,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
         }
       }
     }
+    GEMM_STAMP(7);
   }
 #undef FF_LOAD
 #undef FF_STORE

@@ -20,6 +20,10 @@ if ROT:
 FFN = len(sys.argv) > 1 and sys.argv[1] == "ffn"  # the row-owning ffn[0] + LayerNorm + GELU kernel (N = 512, K = 256 + 256)
 if FFN:
     sys.argv = [sys.argv[0], "512", "512"] + sys.argv[2:]
+MLP = len(sys.argv) > 1 and sys.argv[1] == "mlp"  # the whole-FFN kernel gfc_ffn_fused (round 4): phases of one 128-row item
+if MLP:
+    FFN = True
+    sys.argv = [sys.argv[0], "512", "512"] + sys.argv[2:]
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 256
 M = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
@@ -40,12 +44,19 @@ A1 = torch.randn((M, K // 2), device=dev)
 
 
 cos_t, sin_t = torch.rand((M, 64), device=dev), torch.rand((M, 64), device=dev)
+W3, b3 = torch.randn((256, 512), device=dev) / 512 ** 0.5, torch.randn((256,), device=dev)
+Y2 = torch.empty((M, 256), device=dev)
 
 
 def run():
     if ROT:
         nat.check(lib.gfc_linear(nat.ptr(A), K, K, None, 0, 0, nat.ptr(W), K, nat.ptr(b), None, None, 1.0, None, nat.ptr(cos_t),
                                  nat.ptr(sin_t), 512, nat.ptr(Y), N, M, N, st), "linear")
+        return
+    if MLP:
+        nat.check(lib.gfc_ffn_fused(nat.ptr(A), K, K // 2, nat.ptr(A1), K // 2, K // 2, nat.ptr(W), K, nat.ptr(b),
+                                    nat.ptr(gamma), nat.ptr(beta), nat.ptr(W3), 512, nat.ptr(b3), nat.ptr(A1), nat.ptr(Y2), 256,
+                                    M, st), "mlp")
         return
     if FFN:
         nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(A), K, K // 2, nat.ptr(A1), K // 2, K // 2, nat.ptr(W), K, nat.ptr(b),
@@ -78,6 +89,15 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 np.save(os.path.join(ROOT, "gpurun_out", f"gemm_stamps_N{N}_K{K}.npy"), s)
 t = s[:, :5]
 hw, xcc = s[:, 5], s[:, 6] & 0xF
+if MLP:  # stamps: 0 entry, 1 / 2 first K loop, 3 LayerNorm + GELU done, 4 second K loop done, 7 stores issued
+    t6 = np.concatenate([s[:, :5], s[:, 7:8]], axis=1)
+    d6 = np.diff(t6, axis=1)
+    for name, col in zip(("prologue", "k loop 1", "stats+LN+GELU", "dump + k loop 2", "residual + stores"), range(5)):
+        v = d6[:, col]
+        print(f"{name:18s} median {np.median(v):9.0f}  p10 {np.percentile(v, 10):9.0f}  p90 {np.percentile(v, 90):9.0f} cycles")
+    life6 = t6[:, 5] - t6[:, 0]
+    print(f"wave lifetime median {np.median(life6):.0f}; MFMA cycles per wave {(2048 + 1024) * 64} (first GEMM 131072, second 65536)")
+    sys.exit(0)
 print("waves", len(s), "stamped", int((t[:, 0] > 0).sum()))
 d = np.diff(t, axis=1)
 for name, col in zip(("prologue", "k loop", "statistics" if FFN else "epilogue", "gelu + stores" if FFN else "store drain"), range(4)):
