@@ -254,6 +254,26 @@ def joint_pair_data(data0, data1):
     return joint
 
 
+class DeferredViews:
+    """Per-image results of one extractor call whose key-point counts have not been read yet (run_extractor,
+    defer_counts): `counts` [b] int32 on the device; `finish(lens)` -> the list of per-image prediction dicts."""
+
+    def __init__(self, kout, ksc, desc, counts, core_ms, image, desc_raw, runner):
+        self.kout, self.ksc, self.desc, self.counts = kout, ksc, desc, counts
+        self.core_ms, self.image, self.desc_raw, self.runner = core_ms, image, desc_raw, runner
+
+    def finish(self, lens):
+        preds = []
+        for i, n in enumerate(lens):
+            p_i = {"keypoints": self.kout[i:i + 1, :n], "keypoint_scores": self.ksc[i:i + 1, :n],
+                   "descriptors": self.desc[i:i + 1, :n],
+                   "extractor_core_time_ms": self.image.new_full((1,), self.core_ms)}
+            if self.desc_raw is not None:
+                p_i["dense_descriptors"] = self.runner.l2norm_rows(self.desc_raw[i:i + 1].clone()).permute(0, 3, 1, 2)
+            preds.append(p_i)
+        return preds
+
+
 def extract_views(model, views):
     """`[model(v) for v in views]` (each `v` a single-image extractor input) with ONE extractor call per distinct
     image shape among them: the views are grouped by what must agree inside a call (image shape / dtype / device, which
@@ -270,6 +290,7 @@ def extract_views(model, views):
                tuple((k, tuple(v[k].shape[1:])) for k in ("image_size", "specular_mask") if k in v))
         groups.setdefault(sig, []).append(i)
     out = [None] * len(views)
+    deferred = []
     for sig, idx in groups.items():
         if not sig[3] or len(idx) == 1:  # batched views (or a shape of its own): the ordinary call
             for i in idx:
@@ -280,8 +301,21 @@ def extract_views(model, views):
         for key in ("image_size", "specular_mask"):
             if key in views[idx[0]]:
                 joint[key] = torch.cat([views[i][key].to(dev) for i in idx], 0)
-        for i, pred in zip(idx, model._forward(joint, per_image=True)):
-            out[i] = pred
+        res = model._forward(joint, per_image=True, defer_counts=True)
+        if isinstance(res, DeferredViews):
+            deferred.append((idx, res))
+        else:
+            for i, pred in zip(idx, res):
+                out[i] = pred
+    if deferred:
+        # ONE host synchronisation for the key-point counts of all shape groups (the groups' kernels queue up behind
+        # each other meanwhile) instead of one per extractor call
+        lens = torch.cat([res.counts for _, res in deferred]).tolist()
+        o = 0
+        for idx, res in deferred:
+            for i, pred in zip(idx, res.finish(lens[o:o + len(idx)])):
+                out[i] = pred
+            o += len(idx)
     return out
 
 
@@ -300,13 +334,17 @@ def specular_mask_bytes(data, b, device):
 
 def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection_threshold, max_num_keypoints,
                   force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs, specular=None,
-                  refinement_radius=0, per_image=False):
+                  refinement_radius=0, per_image=False, defer_counts=False):
     """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379).
     specular: None, "before_topk" (superpoint_open.py:177-188) or "after_topk" (superpoint.py:310-328) when
     `data["specular_mask"]` is to be applied.
     per_image: return a list of one prediction dict per image (batch dimension 1 each) instead of one batched dict;
     images may then yield different numbers of key points (two views of a pair extracted by ONE call,
-    two_view_pipeline.py: the reference runs the extractor once per view, so its views never had to agree)."""
+    two_view_pipeline.py: the reference runs the extractor once per view, so its views never had to agree).
+    defer_counts (with per_image, a finite max_num_keypoints and no padding): no host synchronisation here -- every
+    image's slots are sampled up to the cap (beyond its count: zeros) and a `DeferredViews` is returned, whose
+    `finish(lens)` cuts the per-image predictions once the caller has read the counts (extract_views reads the counts of
+    ALL its shape groups with one synchronisation instead of one per extractor call)."""
     image = data["image"]
     nat.require_cuda(image, "data['image']")
     if image.dtype != torch.float32:
@@ -342,6 +380,10 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
         # kept on the device: no host synchronisation on the batched path, one launch
         kpts, ksc = pad_keypoints_native(kpts, ksc, counts, k, 0, data, image)
         counts_arg = None
+    elif defer_counts and per_image and k is not None:
+        desc, kout = runner.sample(desc_raw, kpts, counts, sample_mode)
+        return DeferredViews(kout, ksc, desc, counts, core_time_ms / b, image,
+                             desc_raw if dense_outputs else None, runner)
     else:
         n = counts.tolist()  # host sync, as torch.where in the reference
         if len(set(n)) != 1 and not per_image:

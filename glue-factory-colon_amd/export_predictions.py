@@ -61,24 +61,76 @@ def _process(model, data, keys, optional_keys, callback_fn, as_half):
 
 def _process_batch(model, datas, keys, optional_keys, callback_fn, as_half):
     """`pair_batch` consecutive pairs through one `forward_pairs` call; one record per pair."""
+    return _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half)()
+
+
+class _HostStage:
+    """Per-thread pinned staging buffers (one per dtype, grow-only) and the side stream the record copies run on."""
+
+    def __init__(self):
+        self.local = threading.local()
+
+    def get(self, dtype, numel, device):
+        st = self.local.__dict__
+        if "stream" not in st:
+            st["stream"], st["bufs"] = torch.cuda.Stream(device), {}
+        # two alternating buffers per dtype: batch i's records are still being read while batch i + 1 is copied
+        slot = st.setdefault("turn", {}).get(dtype, 0)
+        st["turn"][dtype] = slot ^ 1
+        buf = st["bufs"].get((dtype, slot))
+        if buf is None or buf.numel() < numel:
+            buf = torch.empty(int(numel * 1.25) + 16, dtype=dtype).pin_memory()
+            st["bufs"][(dtype, slot)] = buf
+        return st["stream"], buf
+
+
+_HOST_STAGE = _HostStage()
+
+
+def _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half):
+    """Forward + record building of one pair batch; returns a function that completes the host copy and yields the
+    records.  ONE device-to-host copy per dtype for the whole batch (instead of one synchronising copy per pair and
+    key), issued on a side stream into pinned memory: the caller may queue the next batch's forward before it calls the
+    function, so that slicing this batch's records overlaps the next batch's kernels."""
     preds = model.forward_pairs(datas) if hasattr(model, "forward_pairs") else [model(d) for d in datas]
     preds = [_record(p, d, keys, optional_keys, callback_fn, as_half, to_host=False) for p, d in zip(preds, datas)]
-    # ONE device-to-host copy per dtype for the whole batch instead of one synchronising copy per pair and key
     by_dtype = {}
     for i, p in enumerate(preds):
         for k, v in p.items():
-            by_dtype.setdefault(v.dtype, []).append((i, k, v[0]))
-    recs = [dict() for _ in preds]
-    for entries in by_dtype.values():
-        flat = torch.cat([t.reshape(-1) for _, _, t in entries]).cpu().numpy()
-        off = 0
-        for i, k, t in entries:
-            recs[i][k] = flat[off:off + t.numel()].reshape(tuple(t.shape)).copy()
-            off += t.numel()
-    recs = [{k: r[k] for k in p} for p, r in zip(preds, recs)]  # key order of the prediction
-    if as_half:
-        recs = [{k: (v.astype(np.float16) if v.dtype == np.float32 else v) for k, v in r.items()} for r in recs]
-    return recs
+            by_dtype.setdefault(v.dtype, []).append((i, k, tuple(v.shape[1:]), v[0].reshape(-1)))
+    staged = []
+    for dtype, entries in by_dtype.items():
+        flat = torch.cat([t for *_, t in entries])
+        if flat.device.type == "cuda":
+            side, host = _HOST_STAGE.get(dtype, flat.numel(), flat.device)
+            side.wait_stream(torch.cuda.current_stream(flat.device))
+            with torch.cuda.stream(side):
+                host[:flat.numel()].copy_(flat, non_blocking=True)
+                done = torch.cuda.Event()
+                done.record(side)
+            flat.record_stream(side)
+            staged.append((entries, host, done))
+        else:
+            staged.append((entries, flat, None))
+    order = [list(p) for p in preds]
+
+    def finish():
+        recs = [dict() for _ in order]
+        for entries, host, done in staged:
+            if done is not None:
+                done.synchronize()
+            arr = host.numpy()
+            off = 0
+            for i, k, shape, t in entries:
+                n = t.numel()
+                recs[i][k] = arr[off:off + n].reshape(shape).copy()
+                off += n
+        out = [{k: r[k] for k in ks} for ks, r in zip(order, recs)]  # key order of the prediction
+        if as_half:
+            out = [{k: (v.astype(np.float16) if v.dtype == np.float32 else v) for k, v in r.items()} for r in out]
+        return out
+
+    return finish
 
 
 def _record(pred, data, keys, optional_keys, callback_fn, as_half, to_host=True):
@@ -274,6 +326,19 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
         return [(idx, name, rec) for (idx, _), name, rec in zip(chunk, names, recs)]
 
     if workers <= 1 or device == "cpu":
+        if pair_batch > 1 and device != "cpu":
+            # software pipeline of depth one: batch i's records are cut on the host while batch i + 1's kernels run
+            pending = None
+            for chunk in _batches(indexed, pair_batch):
+                datas = [_to_device(d, device) for _, d in chunk]
+                names = [d.get("name", [None])[0] for d in datas]
+                fin = _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half)
+                if pending is not None:
+                    out.extend((idx, name, rec) for (idx, _), name, rec in zip(pending[0], pending[1], pending[2]()))
+                pending = (chunk, names, fin)
+            if pending is not None:
+                out.extend((idx, name, rec) for (idx, _), name, rec in zip(pending[0], pending[1], pending[2]()))
+            return
         for chunk in _batches(indexed, pair_batch):
             out.extend(run_chunk(model, chunk))
         return

@@ -88,7 +88,7 @@ class SuperPoint(BaseModel):
                                 cv(self.convPb), cv(self.convDb), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic", None))
 
-    def _forward(self, data, per_image=False):
+    def _forward(self, data, per_image=False, defer_counts=False):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         conf = self.conf
@@ -117,7 +117,7 @@ class SuperPoint(BaseModel):
                 force_num_keypoints=conf_get(conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_LEGACY if conf_get(conf, "legacy_sampling") else SAMPLE_FIXED,
                 use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"), specular=specular,
-                refinement_radius=conf_get(conf, "refinement_radius", 0) or 0, per_image=per_image)
+                refinement_radius=conf_get(conf, "refinement_radius", 0) or 0, per_image=per_image, defer_counts=defer_counts)
 
     def forward_pair(self, data0, data1):
         """Both views of an image pair through ONE extractor call when their images agree in shape (see

@@ -101,7 +101,7 @@ class SuperPoint(BaseModel):
                                 blk(self.descriptor[1]), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic"))
 
-    def _forward(self, data, per_image=False):
+    def _forward(self, data, per_image=False, defer_counts=False):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         specular = "before_topk" if ("specular_mask" in data and conf_get(self.conf, "filter_specular_keypoints")) else None
@@ -118,7 +118,7 @@ class SuperPoint(BaseModel):
                 max_num_keypoints=conf_get(self.conf, "max_num_keypoints"),
                 force_num_keypoints=conf_get(self.conf, "force_num_keypoints"),
                 sample_mode=SAMPLE_OPEN, use_image_size_for_borders=False,
-                dense_outputs=conf_get(self.conf, "dense_outputs"), specular=specular, per_image=per_image)
+                dense_outputs=conf_get(self.conf, "dense_outputs"), specular=specular, per_image=per_image, defer_counts=defer_counts)
 
     def forward_pair(self, data0, data1):
         """Both views of an image pair through ONE extractor call when their images agree in shape (MI355X addition

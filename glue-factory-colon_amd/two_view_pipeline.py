@@ -159,10 +159,9 @@ class TwoViewPipeline(BaseModel):
         (`forward_views`), the matcher ONCE over all N pairs with their own key-point counts (`forward_pairs`,
         gfc_lg_forward_ragged).  Every pair's prediction carries the keys of the single-pair call; the timing /
         memory keys are the batch's figures divided by N (one device-synchronised measurement per stage and batch).
-        Pairs with cached features, batched pairs, or components without the batched entry points take `self(d)`."""
+        Pairs with cached features, batched pairs, or a matcher without `forward_pairs` take `self(d)`."""
         ext, mat = getattr(self, "extractor", None), getattr(self, "matcher", None)
-        ok = (len(datas) > 1 and ext is not None and hasattr(ext, "forward_views")
-              and (mat is None or hasattr(mat, "forward_pairs")))
+        ok = len(datas) > 1 and ext is not None and (mat is None or hasattr(mat, "forward_pairs"))
         for d in datas:
             for key in self.required_data_keys:
                 assert key in d, f"Missing key {key} in data"
@@ -173,7 +172,9 @@ class TwoViewPipeline(BaseModel):
         n = len(datas)
         device = datas[0]["view0"]["image"].device
         views = [d[f"view{i}"] for d in datas for i in ("0", "1")]
-        vpreds, t_ext, mem_ext = self._timed(device, lambda: ext.forward_views(views))
+        # extractors without `forward_views` (DISK: its own chunked batching) run view by view; the matcher is batched either way
+        many = ext.forward_views if hasattr(ext, "forward_views") else (lambda vs: [ext(v) for v in vs])
+        vpreds, t_ext, mem_ext = self._timed(device, lambda: many(views))
         cores = [vp.pop("extractor_core_time_ms", None) for vp in vpreds]
         preds = []
         for j, d in enumerate(datas):

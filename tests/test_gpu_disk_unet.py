@@ -199,6 +199,35 @@ def test_config5_disk_plus_lightglue_pipeline_vs_oracle():
     record("config5_pipeline", matches=int((ref["matches0"] >= 0).sum()), keypoints=int(pred["keypoints0"].shape[1]))
 
 
+def test_config5_pair_batched_equals_pair_by_pair():
+    """Config 5 in the pair-batched evaluation loop: DISK has no `forward_views` (its own chunked batching), so
+    TwoViewPipeline.forward_pairs extracts view by view and still runs the 128-d LightGlue ONCE over all pairs with
+    their own key-point counts: integer outputs identical to the pair-by-pair calls, scores within 1e-4."""
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+    pipe = TwoViewPipeline({
+        "extractor": {"name": "extractors.disk_kornia", "weights": "synthetic", "max_num_keypoints": 384},
+        "matcher": {"name": "matchers.lightglue_pretrained", "features": "disk", "weights": "synthetic",
+                    "filter_threshold": 0.1}}).eval().to(DEV)
+    g = torch.Generator().manual_seed(56)
+    datas = []
+    for h, w in ((160, 208), (176, 240), (160, 208), (208, 160)):
+        img0 = torch.rand((1, 3, h, w), generator=g)
+        img1 = (img0.roll(5, -1) * 0.9 + 0.05 * torch.rand((1, 3, h, w), generator=g)).contiguous()
+        size = torch.tensor([[float(w), float(h)]], device=DEV)
+        datas.append({"view0": {"image": img0.to(DEV), "image_size": size}, "view1": {"image": img1.to(DEV), "image_size": size}})
+    with torch.no_grad():
+        single = [pipe(d) for d in datas]
+        multi = pipe.forward_pairs(datas)
+    assert len({p["keypoints0"].shape[1] for p in single} | {p["keypoints1"].shape[1] for p in single}) > 1  # ragged
+    for a, b in zip(single, multi):
+        assert set(a) == set(b)
+        for k in ("keypoints0", "keypoints1", "descriptors0", "matches0", "matches1"):
+            assert torch.equal(a[k], b[k]), k
+        assert (a["matching_scores0"] - b["matching_scores0"]).abs().max() < 1e-4
+        assert (a["matches0"] >= 0).sum() > 20
+
+
 def test_weights_loaded_through_the_wrapper_replace_the_packed_ones():
     """A forward packs device copies of the weights; weights loaded afterwards through a PARENT module's
     load_state_dict (nn.Module recursion, not DiskUnet's own override) must be the ones the next forward uses."""
