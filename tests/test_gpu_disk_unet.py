@@ -206,7 +206,7 @@ def test_config5_pair_batched_equals_pair_by_pair():
     from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
 
     pipe = TwoViewPipeline({
-        "extractor": {"name": "extractors.disk_kornia", "weights": "synthetic", "max_num_keypoints": 384},
+        "extractor": {"name": "extractors.disk_kornia", "weights": "synthetic", "max_num_keypoints": 4096},
         "matcher": {"name": "matchers.lightglue_pretrained", "features": "disk", "weights": "synthetic",
                     "filter_threshold": 0.1}}).eval().to(DEV)
     g = torch.Generator().manual_seed(56)

@@ -1,5 +1,5 @@
-"""Randomised shape sweep of gfc_conv3x3_wino / gfc_lg_assign / gfc_disk_nms_select / gfc_linear / gfc_attention against
-torch float64 / the oracle
+"""Randomised shape sweep of gfc_conv3x3_wino / gfc_lg_assign / gfc_disk_nms_select / gfc_linear / gfc_attention /
+gfc_ffn_fused / gfc_lg_forward_ragged against torch float64 / the oracle / the single-pair calls
 (run on the GPU box: python tools/micro/fuzz_shapes.py [n_cases]).  Prints the worst error and any failing shape."""
 import ctypes
 import os
@@ -279,6 +279,71 @@ def run(n_cases=60, seed=2024):
             if not err < 2e-5:
                 bad.append(("attention", shapes, (nq, nk), err))
     print("attention: worst", worst, "bad", bad)
+    failures += bad
+
+    # ---- gfc_ffn_fused (whole FFN + residual in one kernel) at any row count, against float64 and the two-kernel path ----
+    bad, worst = [], 0.0
+    for case in range(max(n_cases // 6, 6)):
+        m = [ri(1, 300), ri(300, 5000), 128 * ri(1, 40), 16384 + ri(0, 300)][case % 4]
+        x, msg = torch.randn((m, 256), generator=g), torch.randn((m, 256), generator=g) * 1.5
+        w0, b0 = torch.randn((512, 512), generator=g) / 512 ** 0.5, torch.randn((512,), generator=g)
+        ga, be = torch.rand((512,), generator=g) + 0.5, torch.randn((512,), generator=g) * 0.2
+        w3, b3 = torch.randn((256, 512), generator=g) / 512 ** 0.5, torch.randn((256,), generator=g)
+        dv = [t.to(DEV).contiguous() for t in (x, msg, w0, b0, ga, be, w3, b3)]
+        y = torch.full((m, 256), float("nan"), device=DEV)
+        nat.check(lib.gfc_ffn_fused(nat.ptr(dv[0]), 256, 256, nat.ptr(dv[1]), 256, 256, nat.ptr(dv[2]), 512, nat.ptr(dv[3]),
+                                    nat.ptr(dv[4]), nat.ptr(dv[5]), nat.ptr(dv[6]), 512, nat.ptr(dv[7]), nat.ptr(dv[0]),
+                                    nat.ptr(y), 256, m, st), "ffn_fused")
+        hb = torch.empty((m, 512), device=DEV)
+        nat.check(lib.gfc_linear_layernorm_gelu(nat.ptr(dv[0]), 256, 256, nat.ptr(dv[1]), 256, 256, nat.ptr(dv[2]), 512,
+                                                nat.ptr(dv[3]), nat.ptr(dv[4]), nat.ptr(dv[5]), nat.ptr(hb), 512, m, 512, st), "ln")
+        y2 = torch.empty((m, 256), device=DEV)
+        nat.check(lib.gfc_linear(nat.ptr(hb), 512, 512, None, 0, 0, nat.ptr(dv[6]), 512, nat.ptr(dv[7]), None, None, 1.0,
+                                 nat.ptr(dv[0]), None, None, 0, nat.ptr(y2), 256, m, 256, st), "ffn3")
+        torch.cuda.synchronize()
+        xd, md = x.double(), msg.double()
+        ref = xd + F.linear(F.gelu(F.layer_norm(F.linear(torch.cat([xd, md], 1), w0.double(), b0.double()), (512,),
+                                                ga.double(), be.double(), 1e-5)), w3.double(), b3.double())
+        err = (y.double().cpu() - ref).abs().max().item()
+        worst = max(worst, err if err == err else 0.0)
+        if not err < 3e-5 or not torch.equal(y, y2):
+            bad.append(("ffn_fused", m, err, bool(torch.equal(y, y2))))
+    print("ffn_fused: worst", worst, "bad", bad)
+    failures += bad
+
+    # ---- gfc_lg_forward_ragged: random sets of pairs with their own key-point counts against single-pair calls ----
+    from glue_factory_colon_amd import lightglue
+
+    bad, worst = [], 0.0
+    mods = {d: lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "input_dim": d,
+                                    "n_layers": 3}).eval().to(DEV) for d in (256, 128)}
+    for case in range(max(n_cases // 8, 5)):
+        dim = 256 if case % 3 else 128
+        mdl = mods[dim]
+        nb = ri(2, 7)
+        items = []
+        for _ in range(nb):
+            m_, n_ = (ri(1, 700), ri(1, 700)) if ri(0, 3) else (320, 320)  # some equal shapes: batched assignment groups
+            kp0, kp1 = torch.rand((1, m_, 2), generator=g) * 600, torch.rand((1, n_, 2), generator=g) * 600
+            d0 = F.normalize(torch.randn((1, m_, dim), generator=g), dim=-1)
+            d1 = F.normalize(torch.randn((1, n_, dim), generator=g), dim=-1)
+            size = torch.tensor([[640.0, 480.0]], device=DEV)
+            items.append({"keypoints0": kp0.to(DEV), "keypoints1": kp1.to(DEV), "descriptors0": d0.to(DEV),
+                          "descriptors1": d1.to(DEV), "view0": {"image_size": size}, "view1": {"image_size": size}})
+        with torch.no_grad():
+            single = [mdl(it) for it in items]
+            multi = mdl.forward_pairs(items)
+        torch.cuda.synchronize()
+        for i, (a, b_) in enumerate(zip(single, multi)):
+            same = all(torch.equal(a[k], b_[k]) for k in ("matches0", "matches1"))
+            err = max((a[k] - b_[k]).abs().max().item() if a[k].numel() else 0.0
+                      for k in ("matching_scores0", "matching_scores1", "ref_descriptors0", "ref_descriptors1"))
+            la = ((a["log_assignment"] - b_["log_assignment"]).abs() / (1 + a["log_assignment"].abs())).max().item()
+            worst = max(worst, err, la)
+            if not same or not err < 1e-4 or not la < 1e-4:
+                bad.append(("ragged", dim, [tuple(it["keypoints0"].shape[1:2]) + tuple(it["keypoints1"].shape[1:2]) for it in items],
+                            i, same, err, la))
+    print("ragged forward: worst", worst, "bad", bad)
     return failures + bad
 
 if __name__ == "__main__":
