@@ -837,6 +837,46 @@ def test_lightglue_forward_pairs_scale_ori_and_missing_sizes(golden):
         assert maxerr(a["matching_scores0"], b["matching_scores0"].cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("variant,k,dense", [("open", 300, False), ("open", None, False), ("official", 2000, False),
+                                             ("open", 200, True)])
+def test_forward_views_equals_view_by_view_calls(variant, k, dense):
+    """`forward_views` (one extractor call per distinct image shape, per-image key-point counts, ONE host read of all
+    counts) returns for every view exactly what its own call returns: mixed image shapes, shapes occurring once, views
+    with and without `image_size` / `specular_mask`, a batched view, finite and unlimited `max_num_keypoints`,
+    `dense_outputs`.  Bit-identical (the images of a batch are independent)."""
+    g = torch.Generator().manual_seed(12)
+    conf = {"weights": "synthetic", "max_num_keypoints": k, "detection_threshold": 0.002, "nms_radius": 3,
+            "dense_outputs": dense}
+    m = (spo(**{k_: v for k_, v in conf.items() if k_ != "weights"}) if variant == "open"
+         else superpoint.SuperPoint(conf).eval().to(DEV))
+    views = []
+    for i, (h, w) in enumerate([(96, 128), (120, 96), (96, 128), (96, 128), (64, 200), (120, 96)]):
+        v = {"image": synthetic.synthetic_images(1, h, w, seed=70 + i).to(DEV)}
+        if i % 2 == 0:
+            v["image_size"] = torch.tensor([[float(w - 8 * (i % 4 == 0)), float(h)]], device=DEV)
+        if i in (2, 3):  # two views of one shape with a specular mask (their own group), one of them with image_size
+            v["specular_mask"] = (torch.rand((1, 1, h, w), generator=g) > 0.3).to(DEV)
+        views.append(v)
+    views.append({"image": synthetic.synthetic_images(2, 96, 128, seed=90).to(DEV)})  # a batched view: ordinary call
+    if k is None or variant == "official":
+        views.pop()  # (b = 2 without padding may be ragged: the ordinary call would raise, as the reference's does)
+    with torch.no_grad():
+        single = [m(v) for v in views]
+        multi = m.forward_views(views)
+    assert len(multi) == len(views)
+    lens = set()
+    for a, b in zip(single, multi):
+        assert set(a) == set(b)
+        for key in a:
+            if key == "extractor_core_time_ms":
+                continue
+            assert a[key].shape == b[key].shape, (key, a[key].shape, b[key].shape)
+            assert torch.equal(a[key], b[key]), key
+        lens.add(a["keypoints"].shape[1])
+    if k is None or k >= 2000:
+        assert len(lens) > 2  # below the cap the views keep different numbers of key points
+
+
 @pytest.mark.parametrize("variant", ["open", "official"])
 @pytest.mark.parametrize("threshold,k", [(0.0, 256), (0.001, 2000), (0.001, None)])
 def test_two_view_joint_extraction_equals_sequential(variant, threshold, k):
