@@ -223,6 +223,12 @@ def test_dropin_inside_reference_registry():
         "    'weights': 'synthetic', 'filter_threshold': 0.1}}).eval()\n"
         "assert pipe.extractor.conf.max_num_keypoints == 1024 and pipe.extractor.conf.remove_borders == 4\n"
         "assert pipe.is_initialized()\n"
+        "# this package's pipeline class (the one with forward_pairs, for export_predictions(pair_batch=N)) by name\n"
+        "P = get_model('glue_factory_colon_amd.two_view_pipeline')\n"
+        "assert issubclass(P, BaseModel) and hasattr(P, 'forward_pairs') and not hasattr(TwoViewPipeline, 'forward_pairs')\n"
+        "p2 = P({'extractor': {'name': 'glue_factory_colon_amd.superpoint', 'weights': 'synthetic'},\n"
+        "        'matcher': {'name': 'glue_factory_colon_amd.lightglue', 'weights': 'synthetic'}}).eval()\n"
+        "assert p2.is_initialized() and hasattr(p2.extractor, 'forward_views') and hasattr(p2.matcher, 'forward_pairs')\n"
         "print('DROPIN_OK')\n")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240,
                        env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
