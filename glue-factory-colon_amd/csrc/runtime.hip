@@ -25,6 +25,8 @@ const GfcKnobs& gfc_knobs() {
     g_knobs.assign_mode = env_int("GFC_ASSIGN_MODE", 0);
     g_knobs.gemm_epi = env_int("GFC_GEMM_EPI", 0);
     g_knobs.gemm_stagger = env_int("GFC_GEMM_STAGGER", 0);
+    g_knobs.nms_mode = env_int("GFC_NMS_MODE", 0);
+    g_knobs.nms_stream_min_tasks = env_int("GFC_NMS_STREAM_MIN_TASKS", 0);
     g_knobs.stem_f43 = env_int("GFC_STEM_F43", 1);
     g_knobs.xcd_remap = env_int("GFC_XCD_REMAP", 1);
   });

@@ -2,6 +2,9 @@
 // All HBM-bound byte/compare work: coalesced loads into LDS, wavefront reductions, no GEMM shapes.
 #include "common.h"
 
+#include <type_traits>
+#include <utility>
+
 // ------------------------------------------------------------------------------------------
 // softmax over 65 logits per 8x8 cell, drop the dustbin, depth-to-space:
 //   S[b, 8y+i, 8x+j] = P[b, 8i+j, y, x]      (superpoint_open.py:139-144; superpoint.py:231-235)
@@ -221,6 +224,212 @@ __global__ __launch_bounds__(1024) void nms_kernel(const float* __restrict__ hea
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Streaming NMS (round 4): the same five dependent pools, but without the LDS image and its ten passes.  One WAVE owns a
+// band of 64 columns (lane = column, 64 - 10 r of them stored) and walks down a segment of 64 output rows (+ 5 r halo
+// rows above and below): the horizontal half of every pool is two or three wave shifts (DPP wave_shr / wave_shl) and a
+// v_max3 / v_or3, the vertical half a v_max3 tree over a ring of the last 2 r + 1 rows kept IN REGISTERS (the row loop is
+// unrolled by the ring length, so every ring index is a compile-time constant).  Stage k of the chain runs k r rows
+// behind the row being loaded:
+//   row y1 = row - r:   keep0 = s == mp(s)                    row y2 = row - 2r:  near1 = mp(keep0) > 0, t1 = near1 ? 0 : s
+//   row y3 = row - 3r:  keep1 = keep0 | (t1 == mp(t1) & ~near1)   row y4 = row - 4r:  near2 = mp(keep1) > 0, t2 = ...
+//   row y5 = row - 5r:  keep2 = keep1 | (t2 == mp(t2) & ~near2);  out = keep2 ? s : 0, border kill, candidate emission
+// The same fp32 equality tests on the same values as nms_kernel: bit-identical output (test_nms_golden_bit_exact runs
+// both).  No barrier, no shared image: 64 VGA images 344 us -> see DESIGN.md section 9.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpp_shr1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x138, 0xf, 0xf, false); }  // x[lane - 1]
+__device__ __forceinline__ int dpp_shl1(int x, int fill) { return __builtin_amdgcn_update_dpp(fill, x, 0x130, 0xf, 0xf, false); }  // x[lane + 1]
+template <int K>
+__device__ __forceinline__ float fshr(float x) {
+  int v = __float_as_int(x);
+#pragma unroll
+  for (int i = 0; i < K; ++i) v = dpp_shr1(v, (int)0xff800000);
+  return __int_as_float(v);
+}
+template <int K>
+__device__ __forceinline__ float fshl(float x) {
+  int v = __float_as_int(x);
+#pragma unroll
+  for (int i = 0; i < K; ++i) v = dpp_shl1(v, (int)0xff800000);
+  return __int_as_float(v);
+}
+template <int K>
+__device__ __forceinline__ int ishr(int v) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) v = dpp_shr1(v, 0);
+  return v;
+}
+template <int K>
+__device__ __forceinline__ int ishl(int v) {
+#pragma unroll
+  for (int i = 0; i < K; ++i) v = dpp_shl1(v, 0);
+  return v;
+}
+// max / OR over lanes l - RAD .. l + RAD
+template <int RAD>
+__device__ __forceinline__ float hwin(float x) {
+  const float a = fmaxf(fmaxf(x, fshr<1>(x)), fshl<1>(x));
+  if constexpr (RAD == 1) return a;
+  else if constexpr (RAD == 2) return fmaxf(fmaxf(a, fshr<1>(a)), fshl<1>(a));
+  else if constexpr (RAD == 3) return fmaxf(fmaxf(a, fshr<2>(a)), fshl<2>(a));
+  else return fmaxf(fmaxf(a, fshr<3>(a)), fshl<3>(a));
+}
+template <int RAD>
+__device__ __forceinline__ int hwin(int x) {
+  const int a = x | ishr<1>(x) | ishl<1>(x);
+  if constexpr (RAD == 1) return a;
+  else if constexpr (RAD == 2) return a | ishr<1>(a) | ishl<1>(a);
+  else if constexpr (RAD == 3) return a | ishr<2>(a) | ishl<2>(a);
+  else return a | ishr<3>(a) | ishl<3>(a);
+}
+template <int L>
+__device__ __forceinline__ float vwin(const float (&r)[L]) {
+  float m = r[0];
+#pragma unroll
+  for (int i = 1; i < L; ++i) m = fmaxf(m, r[i]);
+  return m;
+}
+template <int L>
+__device__ __forceinline__ int vwin(const int (&r)[L]) {
+  int m = r[0];
+#pragma unroll
+  for (int i = 1; i < L; ++i) m |= r[i];
+  return m;
+}
+
+#define NMS_SEGH 64
+// L consecutive rows with compile-time ring indices 0 .. L - 1
+template <typename F, int... Is>
+__device__ __forceinline__ void nms_unrolled_rows(F& f, int r, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}, r + Is), ...);
+}
+template <int RAD>
+struct NmsStreamState {
+  static constexpr int L = 2 * RAD + 1;
+  float sr[L], srb[L], src[L], hs[L], t1[L], ht1[L], t2[L], ht2[L];  // sr / srb / src: s of rows r, r - L, r - 2L
+  int k0[L], hk0[L], n1[L], k1[L], hk1[L], n2[L];
+};
+
+template <int RAD>
+__global__ __launch_bounds__(256) void nms_stream_kernel(const float* __restrict__ heat, int H, int W, int border,
+                                                         const int* __restrict__ valid_wh, float* __restrict__ out,
+                                                         float cand_thr, unsigned long long* __restrict__ cand,
+                                                         int* __restrict__ cand_count, int bands, int ntasks) {
+  constexpr int L = 2 * RAD + 1, HALO = 5 * RAD, BW = 64 - 2 * HALO;
+  __shared__ unsigned long long cbuf[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int task = blockIdx.x * 4 + wave, b = blockIdx.y;
+  if (task >= ntasks) return;  // (wave-uniform; no barrier in this kernel)
+  const int bx = task % bands, sy = task / bands;
+  const int col = bx * BW - HALO + lane;
+  const bool col_in = col >= 0 && col < W;
+  const bool lane_out = lane >= HALO && lane < 64 - HALO && col < W;
+  const int y0 = sy * NMS_SEGH;
+  const int y_end = min(y0 + NMS_SEGH, H);
+  const float* hb = heat + (size_t)b * H * W;
+  float* ob = out ? out + (size_t)b * H * W : nullptr;
+  int vw = W, vh = H;
+  if (valid_wh) { vw = valid_wh[2 * b]; vh = valid_wh[2 * b + 1]; }
+  unsigned long long* cb = cbuf[wave];
+  int ccnt = 0;
+  auto flush = [&]() __attribute__((always_inline)) {
+    if (ccnt > 0) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&cand_count[b], ccnt);
+      base = __builtin_amdgcn_readfirstlane(base);
+      for (int i = lane; i < ccnt; i += 64) cand[(size_t)b * H * W + base + i] = cb[i];
+      ccnt = 0;
+    }
+  };
+  auto load_s = [&](int y) __attribute__((always_inline)) -> float {
+    return (y >= 0 && y < H && col_in) ? hb[(size_t)y * W + col] : -INFINITY;
+  };
+
+  NmsStreamState<RAD> st;
+#pragma unroll
+  for (int i = 0; i < L; ++i) {
+    st.sr[i] = st.srb[i] = st.src[i] = st.hs[i] = st.t1[i] = st.ht1[i] = st.t2[i] = st.ht2[i] = -INFINITY;
+    st.k0[i] = st.hk0[i] = st.n1[i] = st.k1[i] = st.hk1[i] = st.n2[i] = 0;
+  }
+  // one row of the chain; I = (row - first row) mod L (compile time): ring slot of row - k RAD is (I - k RAD) mod L
+  float pre[L];  // the next L rows of s, requested one group of rows ahead
+  auto step = [&](auto Ic, int row) __attribute__((always_inline)) {
+    constexpr int I = decltype(Ic)::value;
+    constexpr int I1 = ((I - RAD) % L + L) % L, I2 = ((I - 2 * RAD) % L + L) % L, I3 = ((I - 3 * RAD) % L + L) % L;
+    constexpr int I4 = ((I - 4 * RAD) % L + L) % L, I5 = ((I - 5 * RAD) % L + L) % L;
+    const float s0 = pre[I];
+    pre[I] = load_s(row + L);
+    // s of rows r - L and r - 2L moves on through two more rings: the far delays 4 RAD (L <= 4 RAD < 2L) and 5 RAD
+    // (L < 5 RAD < 3L) are read from them instead of from memory again.  Slot I of each ring is free at this point.
+    st.src[I] = st.srb[I];
+    st.srb[I] = st.sr[I];
+    st.sr[I] = s0;
+    const float s4 = st.srb[I4];  // row - 4 RAD = (row - L) - (4 RAD - L): written 4 RAD - L steps ago
+    const float s5 = 5 * RAD < 2 * L ? st.srb[I5] : st.src[I5];
+    st.hs[I] = hwin<RAD>(s0);
+    {  // y1 = row - RAD: keep0
+      const float m1 = vwin<L>(st.hs), sv = st.sr[I1];
+      const int k = (sv == m1 && sv != -INFINITY) ? 1 : 0;
+      st.k0[I1] = k;
+      st.hk0[I1] = hwin<RAD>(k);
+    }
+    {  // y2 = row - 2 RAD: near1, supp scores t1
+      const int near = vwin<L>(st.hk0);
+      const float sv = st.sr[I2];
+      st.n1[I2] = near;
+      const float t = (sv == -INFINITY) ? sv : (near ? 0.f : sv);
+      st.t1[I2] = t;
+      st.ht1[I2] = hwin<RAD>(t);
+    }
+    {  // y3 = row - 3 RAD: keep1
+      const float m2 = vwin<L>(st.ht1), t = st.t1[I3];
+      int k = st.k0[I3];
+      if (!st.n1[I3] && t == m2 && t != -INFINITY) k = 1;  // (t != -inf <=> the pixel is inside the image)
+      st.k1[I3] = k;
+      st.hk1[I3] = hwin<RAD>(k);
+    }
+    {  // y4 = row - 4 RAD: near2, supp scores t2
+      const int near = vwin<L>(st.hk1);
+      st.n2[I4] = near;
+      const float t = (s4 == -INFINITY) ? s4 : (near ? 0.f : s4);
+      st.t2[I4] = t;
+      st.ht2[I4] = hwin<RAD>(t);
+    }
+    {  // y5 = row - 5 RAD: keep2 -> output
+      const float m3 = vwin<L>(st.ht2), t = st.t2[I5];
+      int k = st.k1[I5];
+      if (!st.n2[I5] && t == m3 && t != -INFINITY) k = 1;
+      const int y = row - 5 * RAD;
+      if (y >= y0 && y < y_end) {  // wave-uniform
+        float v = k ? s5 : 0.f;
+        if (border > 0 && (y < border || col < border || y >= vh - border || col >= vw - border)) v = -1.f;
+        if (lane_out && ob) ob[(size_t)y * W + col] = v;
+        if (cand) {
+          const bool c = lane_out && v > cand_thr;
+          const unsigned long long mask = __ballot(c);
+          const int n = __popcll(mask);
+          if (ccnt + n > 256) flush();
+          if (c) {
+            const unsigned int idx = (unsigned int)(y * W + col);
+            cb[ccnt + __popcll(mask & ((1ull << lane) - 1ull))] =
+                ((unsigned long long)float_order_bits(v) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+          }
+          ccnt += n;
+        }
+      }
+    }
+  };
+  // k1 at y3 needs the keep0 of y3, which was written 2 RAD rows ago, and st.k0[I3] is the slot written then: the ring
+  // slots of a quantity are L = 2 RAD + 1 apart in rows, so a value written at row r is intact until row r + 2 RAD.
+  const int r_begin = y0 - 5 * RAD, r_stop = y_end + 5 * RAD;  // rows r_begin .. r_stop - 1 are loaded
+#pragma unroll
+  for (int i = 0; i < L; ++i) pre[i] = load_s(r_begin + i);
+  for (int r = r_begin; r < r_stop; r += L) {
+    nms_unrolled_rows(step, r, std::make_integer_sequence<int, L>{});
+  }
+  if (cand) flush();
+}
+
 // radius 0: the pools are identities -> only the border kill remains
 __global__ void nms_r0_kernel(const float* __restrict__ heat, int H, int W, int border,
                               const int* __restrict__ valid_wh, float* __restrict__ out, float cand_thr,
@@ -246,6 +455,19 @@ static int launch_nms(const float* heat, int B, int H, int W, int border, const 
                       float cand_thr, unsigned long long* cand, int* cand_count, hipStream_t st) {
   constexpr int R = NT + 10 * RAD, RS = R | 1;
   const size_t lds = (size_t)R * RS * (3 * sizeof(float) + 2);
+  // default: the streaming kernel once its waves cover the chip a few times over (a wave walks ~64 + 10 r rows in
+  // sequence: with few tasks the LDS-image kernel's wider parallelism wins -- 2 VGA images: 17 us against 44 us, 64
+  // images: 328 us against 194 us).  GFC_NMS_MODE = 1: always the LDS-image kernel of round 1, 2: always streaming.
+  constexpr int BW = 64 - 10 * RAD;
+  const int bands = (W + BW - 1) / BW, segs = (H + NMS_SEGH - 1) / NMS_SEGH, ntasks = bands * segs;
+  const int mode = gfc_knobs().nms_mode;
+  const long long thr = gfc_knobs().nms_stream_min_tasks > 0 ? gfc_knobs().nms_stream_min_tasks : 1800;
+  if (mode == 2 || (mode == 0 && (long long)ntasks * B >= thr)) {
+    hipLaunchKernelGGL(nms_stream_kernel<RAD>, dim3((ntasks + 3) / 4, B), dim3(256), 0, st, heat, H, W, border, valid_wh, out,
+                       cand_thr, cand, cand_count, bands, ntasks);
+    GFC_LAUNCH_CHECK();
+    return GFC_OK;
+  }
   static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
   if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)nms_kernel<RAD>, lds, lds_ok);
   dim3 grid(((W + NT - 1) / NT) * ((H + NT - 1) / NT), B);

@@ -728,7 +728,8 @@ def test_nms_golden_bit_exact(golden, r):
     assert torch.equal(out.cpu(), gd[f"out_r{r}"])
 
 
-@pytest.mark.parametrize("r,h,w", [(3, 480, 640), (4, 100, 77), (2, 33, 200)])
+@pytest.mark.parametrize("r,h,w", [(3, 480, 640), (4, 100, 77), (2, 33, 200), (1, 5, 3), (3, 1, 300), (4, 130, 24),
+                                   (3, 65, 35), (1, 64, 108), (2, 200, 45)])
 def test_nms_large_vs_oracle(r, h, w):
     lib = nat.lib()
     g = gen(r * 100 + h)
@@ -788,6 +789,43 @@ def test_fused_nms_select_equals_separate_stages(k, r):
     torch.cuda.synchronize()
     assert torch.equal(cnt_a, cnt_b) and torch.equal(kp_a, kp_b) and torch.equal(sc_a, sc_b)
     assert int(cnt_a[2]) < k
+
+
+def test_fused_nms_select_candidate_overflow_paths():
+    """The streaming NMS buffers its candidates per wave (256 slots) and reserves list space with one atomic per flush: a
+    NEGATIVE detection threshold makes every pixel a candidate (zeros included), so every wave flushes several times, and
+    the result must still equal the separate stages.  Also k larger than the number of candidates and a 1-row image."""
+    from glue_factory_colon_amd._superpoint_common import SuperPointRunner
+
+    g = gen(91)
+    run = SuperPointRunner()
+    for (h, w, r, th, k) in ((96, 130, 3, -0.5, 4000), (70, 64, 2, -2.0, 8192), (1, 500, 1, 0.0, 100), (40, 40, 4, 0.0, 8192)):
+        s = torch.rand((2, h, w), generator=g)
+        s[1] = (s[1] * 8).round() / 8
+        sd = D(s)
+        nms = run.nms(sd, r, 2, None)
+        kp_a, sc_a, cnt_a = run.select(nms, th, k)
+        kp_b, sc_b, cnt_b = run.nms_select(sd, r, 2, None, th, k)
+        torch.cuda.synchronize()
+        assert torch.equal(cnt_a, cnt_b), (h, w, r, cnt_a, cnt_b)
+        for i in range(2):
+            n = int(cnt_a[i])
+            assert torch.equal(kp_a[i, :n], kp_b[i, :n]) and torch.equal(sc_a[i, :n], sc_b[i, :n]), (h, w, r, i)
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_nms_kernel_variants_via_knob(mode):
+    """The default picks the NMS kernel by problem size (few images: 64 x 64 tiles on an LDS image, ten passes; many:
+    the streaming kernel -- waves walk column bands with the pool windows in registers).  GFC_NMS_MODE=1 / 2 force one
+    of them for every size: both pass the same bit-exact tests."""
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GFC_NMS_MODE=mode)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "(test_nms_golden or test_nms_large or test_fused_nms_select or test_select_bit_exact) and not via_knob",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-800:], r.stderr[-400:])
 
 
 def test_select_ties_and_empty():
