@@ -314,7 +314,7 @@ template <int RAD>
 __global__ __launch_bounds__(256) void nms_stream_kernel(const float* __restrict__ heat, int H, int W, int border,
                                                          const int* __restrict__ valid_wh, float* __restrict__ out,
                                                          float cand_thr, unsigned long long* __restrict__ cand,
-                                                         int* __restrict__ cand_count, int bands, int ntasks) {
+                                                         int* __restrict__ cand_count, int bands, int ntasks, int segh) {
   constexpr int L = 2 * RAD + 1, HALO = 5 * RAD, BW = 64 - 2 * HALO;
   __shared__ unsigned long long cbuf[4][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,8 +324,8 @@ __global__ __launch_bounds__(256) void nms_stream_kernel(const float* __restrict
   const int col = bx * BW - HALO + lane;
   const bool col_in = col >= 0 && col < W;
   const bool lane_out = lane >= HALO && lane < 64 - HALO && col < W;
-  const int y0 = sy * NMS_SEGH;
-  const int y_end = min(y0 + NMS_SEGH, H);
+  const int y0 = sy * segh;
+  const int y_end = min(y0 + segh, H);
   const float* hb = heat + (size_t)b * H * W;
   float* ob = out ? out + (size_t)b * H * W : nullptr;
   int vw = W, vh = H;
@@ -459,12 +459,16 @@ static int launch_nms(const float* heat, int B, int H, int W, int border, const 
   // sequence: with few tasks the LDS-image kernel's wider parallelism wins -- 2 VGA images: 17 us against 44 us, 64
   // images: 328 us against 194 us).  GFC_NMS_MODE = 1: always the LDS-image kernel of round 1, 2: always streaming.
   constexpr int BW = 64 - 10 * RAD;
-  const int bands = (W + BW - 1) / BW, segs = (H + NMS_SEGH - 1) / NMS_SEGH, ntasks = bands * segs;
+  const int bands = (W + BW - 1) / BW;
+  // rows per wave task: 64 (+ 10 r halo rows recomputed), or 128 once that still leaves >= 4 tasks per SIMD
+  int segh = NMS_SEGH;
+  if ((long long)bands * ((H + 127) / 128) * B >= 4096) segh = 128;
+  const int segs = (H + segh - 1) / segh, ntasks = bands * segs;
   const int mode = gfc_knobs().nms_mode;
   const long long thr = gfc_knobs().nms_stream_min_tasks > 0 ? gfc_knobs().nms_stream_min_tasks : 1800;
-  if (mode == 2 || (mode == 0 && (long long)ntasks * B >= thr)) {
+  if (mode == 2 || (mode == 0 && (long long)bands * ((H + NMS_SEGH - 1) / NMS_SEGH) * B >= thr)) {
     hipLaunchKernelGGL(nms_stream_kernel<RAD>, dim3((ntasks + 3) / 4, B), dim3(256), 0, st, heat, H, W, border, valid_wh, out,
-                       cand_thr, cand, cand_count, bands, ntasks);
+                       cand_thr, cand, cand_count, bands, ntasks, segh);
     GFC_LAUNCH_CHECK();
     return GFC_OK;
   }
