@@ -1,0 +1,47 @@
+"""The driver's contract with bench.py, checked on the GPU box: `python bench.py --steps K --warmup W` prints ONE JSON line
+on stdout with the agreed keys (metric / value / unit / n_gpus / steps / warmup / ms_per_step / higher_is_better / scaling /
+vs_baseline / dtype / data / config.workload + the `roofline` and `cpu_baseline` objects), `value` consistent with
+`ms_per_step`, the roofline fraction a fraction, and the information-only legs present and never the headline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_line_contract():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-iters", "1"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines  # exactly one line on stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "BASELINE.json configs[1]" in d["config"]["workload"] and "model" not in d["config"]
+    pairs = d["config"]["pairs_per_gpu_per_step"]
+    assert abs(d["value"] - pairs / (d["ms_per_step"] * 1e-3)) < 0.01 * d["value"]  # value = pairs / time
+    assert 300 < d["value"] < 5000
+    roof = d["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in roof, key
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 157.3
+    assert 0.3 < roof["frac"] <= 1.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    assert roof["launches_timed"] == 18 * 3  # live HIP events around every attention launch of the timed region
+    cpu = d["cpu_baseline"]
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in cpu, key
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
+    assert d["self_check"]["pairs_equal"] is True and d["self_check"]["keypoint_sets_equal"] is True
+    # information-only legs: present, with their own units, never the headline value
+    for key in ("batch1", "c3_regime", "c4", "config5"):
+        assert key in d and "error" not in d[key], (key, d.get(key))
+    assert d["c3_regime"]["pair_batch32"] > d["c3_regime"]["sequential"] and d["c3_regime"]["same_match_count"] is True
+    assert d["c4"]["keypoints"] == 2048 and d["c4"]["image"] == [1024, 1024]
