@@ -186,7 +186,7 @@ def batch1_latency(dev, n_pairs: int = 24, warmup: int = 4):
 
 
 
-def c3_regime(dev, n_pairs: int = 64):
+def c3_regime(dev, n_pairs: int = 128):
     """Information only (never `value`): BASELINE config 3's regime -- the HPatches evaluation loop
     (utils/export_predictions.py:36-85: batch 1 because the IMAGES differ in size; official SuperPoint + LightGlue,
     1024 key points, detection threshold 0) on an HPatches-shaped list of mixed image shapes, through this package's
