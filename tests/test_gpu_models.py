@@ -806,6 +806,31 @@ def test_lightglue_forward_pairs_ragged_equals_single_pair_calls(golden, dim):
         check_lg(multi[0], g, "d128_")
 
 
+def test_lightglue_forward_pairs_more_pairs_than_one_ragged_call_takes():
+    """More pairs than GFC_LG_MAX_RAGGED_PAIRS (128): forward_pairs splits them over several gfc_lg_forward_ragged calls and
+    still returns one result per pair, in order, equal to the single-pair calls."""
+    from glue_factory_colon_amd import _native as nat
+
+    g = torch.Generator().manual_seed(31)
+    m = lightglue.LightGlue({"weights": "synthetic", "filter_threshold": 0.1, "n_layers": 2}).eval().to(DEV)
+    size = torch.tensor([[320.0, 240.0]], device=DEV)
+    items = []
+    for i in range(nat.GFC_LG_MAX_RAGGED_PAIRS + 7):
+        a, b = 8 + (i * 7) % 23, 5 + (i * 5) % 19
+        items.append({"keypoints0": (torch.rand((1, a, 2), generator=g) * 200).to(DEV),
+                      "keypoints1": (torch.rand((1, b, 2), generator=g) * 200).to(DEV),
+                      "descriptors0": torch.nn.functional.normalize(torch.randn((1, a, 256), generator=g), dim=-1).to(DEV),
+                      "descriptors1": torch.nn.functional.normalize(torch.randn((1, b, 256), generator=g), dim=-1).to(DEV),
+                      "view0": {"image_size": size}, "view1": {"image_size": size}})
+    multi = m.forward_pairs(items)
+    assert len(multi) == len(items)
+    for i in (0, 1, 63, 127, 128, 129, len(items) - 1):
+        a = m(items[i])
+        assert multi[i]["matches0"].shape == a["matches0"].shape
+        assert torch.equal(a["matches0"], multi[i]["matches0"]) and torch.equal(a["matches1"], multi[i]["matches1"])
+        assert maxerr(a["matching_scores0"], multi[i]["matching_scores0"]) < 1e-4
+
+
 def test_lightglue_forward_pairs_scale_ori_and_missing_sizes(golden):
     """forward_pairs with `add_scale_ori` (4-d positional input, lightglue.py:436-453; reference vectors scale_ori.npz)
     and with views that carry no image_size (normalisation by the key points' extent, lightglue.py:31-32)."""
