@@ -298,7 +298,10 @@ def test_export_predictions_sharded_world2_gloo(tmp_path):
         "rank, world, _ = sharding.init_from_env('gloo')\n"
         "out = sys.argv[1]\n"
         "export_predictions(items, Fake(), out + '/sharded.npz', keys=keys)\n"
+        "export_predictions(items, Fake(), out + '/sharded_pb.npz', keys=keys, pair_batch=2)  # chunks of two pairs per rank\n"
         "if rank == 0:\n"
+        "    c = load_predictions(out + '/sharded_pb.npz'); a0 = load_predictions(out + '/sharded.npz')\n"
+        "    assert list(c) == list(a0) and all(np.array_equal(c[n][k], a0[n][k]) for n in c for k in c[n])\n"
         "    export_predictions(items, Fake(), out + '/single.npz', keys=keys, rank=0, world=1)\n"
         "    a, b = load_predictions(out + '/sharded.npz'), load_predictions(out + '/single.npz')\n"
         "    assert list(a) == list(b) == [f'v_seq{i // 3}/{i % 3 + 2}.ppm' for i in range(7)], list(a)\n"
