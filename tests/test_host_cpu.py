@@ -341,11 +341,12 @@ def test_export_predictions_sharded_failure_does_not_hang(tmp_path):
         "items = [{'name': [f's/{i}.ppm'], 'view0': {'x': torch.ones(1, 3, 2), 'scales': torch.ones(1, 2)}} for i in range(4)]\n"
         "try:\n"
         "    export_predictions(items, Fake(), sys.argv[1] + '/p.npz')\n"
-        "    print('NO_EXCEPTION', rank)\n"
+        "    msg = f'NO_EXCEPTION {rank}'\n"
         "except ValueError as e:\n"
-        "    print('OWN_FAILURE', rank, e)\n"
+        "    msg = f'OWN_FAILURE {rank} {e}'\n"
         "except RuntimeError as e:\n"
-        "    print('TOLD', rank, e)\n"
+        "    msg = f'TOLD {rank} {e}'\n"
+        "open(sys.argv[1] + f'/rank{rank}.txt', 'w').write(msg)  # (the ranks' stdout lines may interleave)\n"
         "assert not os.path.exists(sys.argv[1] + '/p.npz')\n"
         "torch.distributed.barrier()\n")
     port = _free_port()
@@ -354,7 +355,9 @@ def test_export_predictions_sharded_failure_does_not_hang(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "OWN_FAILURE 1 boom on rank 1" in r.stdout and "TOLD 0" in r.stdout and "another rank failed" in r.stdout
+    said = [(tmp_path / f"rank{i}.txt").read_text() for i in range(2)]
+    assert said[1] == "OWN_FAILURE 1 boom on rank 1", said
+    assert said[0].startswith("TOLD 0") and "another rank failed" in said[0], said
 
 
 def test_hdf5_prediction_file_without_h5py(tmp_path):
