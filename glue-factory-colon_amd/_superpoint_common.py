@@ -291,22 +291,61 @@ def extract_views(model, views):
         groups.setdefault(sig, []).append(i)
     out = [None] * len(views)
     deferred = []
+    shared = [idx for sig, idx in groups.items() if sig[3] and len(idx) > 1]
+    # Two shape groups in flight: the groups are independent, so they alternate between two side streams (each with its
+    # own runner = its own workspaces) and fill each other's ramps and tails (a group of ~13 VGA images is a small
+    # batch for the chip).  Only with deferred counts -- no host synchronisation between the groups -- i.e. a finite
+    # max_num_keypoints; $GFC_SP_VIEW_STREAMS=0 keeps everything on the caller's stream.
+    lanes = None
+    if len(shared) > 1 and os.environ.get("GFC_SP_VIEW_STREAMS", "1") != "0":
+        dev0 = views[shared[0][0]]["image"].device
+        if dev0.type == "cuda":
+            lanes = getattr(model, "_view_lanes", None)
+            if lanes is None or lanes[0][0].device != dev0:
+                lanes = [(torch.cuda.Stream(dev0), SuperPointRunner()) for _ in range(2)]
+                model._view_lanes = lanes
+    main = torch.cuda.current_stream(dev0) if lanes else None
+    used = set()
+    n_shared = 0
     for sig, idx in groups.items():
         if not sig[3] or len(idx) == 1:  # batched views (or a shape of its own): the ordinary call
             for i in idx:
                 out[i] = model(views[i])
             continue
         dev = views[idx[0]]["image"].device
-        joint = {"image": torch.cat([views[i]["image"] for i in idx], 0)}
-        for key in ("image_size", "specular_mask"):
-            if key in views[idx[0]]:
-                joint[key] = torch.cat([views[i][key].to(dev) for i in idx], 0)
-        res = model._forward(joint, per_image=True, defer_counts=True)
+
+        def run_group(runner):
+            joint = {"image": torch.cat([views[i]["image"] for i in idx], 0)}
+            for key in ("image_size", "specular_mask"):
+                if key in views[idx[0]]:
+                    joint[key] = torch.cat([views[i][key].to(dev) for i in idx], 0)
+            return model._forward(joint, per_image=True, defer_counts=True, runner=runner)
+
+        if lanes:
+            stream, runner = lanes[n_shared % 2]
+            n_shared += 1
+            if id(stream) not in used:
+                stream.wait_stream(main)  # the views' tensors were produced on the caller's stream
+                used.add(id(stream))
+            with torch.cuda.stream(stream):
+                res = run_group(runner)
+            if not isinstance(res, DeferredViews):  # (unlimited key points: per-image results with a host sync; rare)
+                main.wait_stream(stream)
+        else:
+            res = run_group(None)
         if isinstance(res, DeferredViews):
             deferred.append((idx, res))
         else:
             for i, pred in zip(idx, res):
                 out[i] = pred
+    if lanes:
+        for stream, _ in lanes:
+            if id(stream) in used:
+                main.wait_stream(stream)
+        for _, res in deferred:  # allocated on a side stream, consumed on the caller's from here on
+            for t in (res.kout, res.ksc, res.desc, res.counts, res.desc_raw):
+                if t is not None:
+                    t.record_stream(main)
     if deferred:
         # ONE host synchronisation for the key-point counts of all shape groups (the groups' kernels queue up behind
         # each other meanwhile) instead of one per extractor call

@@ -41,13 +41,18 @@ def _replicate(model):
     device pointers into the original's tensors) are dropped so that the copy packs its own on first use."""
     # a model that has already run holds ctypes parameter structs in `_packed` (not copyable): set aside for the copy
     stash = [(m, m._packed) for m in model.modules() if getattr(m, "_packed", None) is not None]
+    lanes = [(m, m._view_lanes) for m in model.modules() if getattr(m, "_view_lanes", None) is not None]
     for m, _ in stash:
         m._packed = None
+    for m, _ in lanes:  # side streams + runners of forward_views: per model instance, rebuilt by the copy on first use
+        m._view_lanes = None
     try:
         rep = copy.deepcopy(model)
     finally:
         for m, packed in stash:
             m._packed = packed
+        for m, l in lanes:
+            m._view_lanes = l
     for m in rep.modules():
         if hasattr(m, "_packed"):
             m._packed = None

@@ -88,7 +88,7 @@ class SuperPoint(BaseModel):
                                 cv(self.convPb), cv(self.convDb), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic", None))
 
-    def _forward(self, data, per_image=False, defer_counts=False):
+    def _forward(self, data, per_image=False, defer_counts=False, runner=None):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         conf = self.conf
@@ -111,7 +111,7 @@ class SuperPoint(BaseModel):
         k = None if (max_kps is None or max_kps <= 0) else int(max_kps)
         with torch.no_grad():
             return run_extractor(
-                self._runner, self._packed, data,
+                runner or self._runner, self._packed, data,
                 nms_radius=conf_get(conf, "nms_radius"), remove_borders=conf_get(conf, "remove_borders"),
                 detection_threshold=conf_get(conf, "detection_threshold"), max_num_keypoints=k,
                 force_num_keypoints=conf_get(conf, "force_num_keypoints"),

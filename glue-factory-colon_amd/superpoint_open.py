@@ -101,7 +101,7 @@ class SuperPoint(BaseModel):
                                 blk(self.descriptor[1]), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic"))
 
-    def _forward(self, data, per_image=False, defer_counts=False):
+    def _forward(self, data, per_image=False, defer_counts=False, runner=None):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         specular = "before_topk" if ("specular_mask" in data and conf_get(self.conf, "filter_specular_keypoints")) else None
@@ -111,7 +111,7 @@ class SuperPoint(BaseModel):
             self._packed = self._pack(device)
         with torch.no_grad():
             return run_extractor(
-                self._runner, self._packed, data,
+                runner or self._runner, self._packed, data,
                 nms_radius=conf_get(self.conf, "nms_radius"),
                 remove_borders=conf_get(self.conf, "remove_borders"),
                 detection_threshold=conf_get(self.conf, "detection_threshold"),
