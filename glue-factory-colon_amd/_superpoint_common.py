@@ -292,14 +292,21 @@ def extract_views(model, views):
     out = [None] * len(views)
     deferred = []
     shared = [idx for sig, idx in groups.items() if sig[3] and len(idx) > 1]
+    # The weights are packed HERE, on the caller's stream, before any group is handed to a side stream: packing is a
+    # sequence of kernels, and a lane that waited only on the caller's stream would otherwise read filters another lane
+    # is still packing (round-4 finding: a never-run model whose first call was forward_views).
+    for idx in shared:
+        if views[idx[0]]["image"].device.type == "cuda":  # (anything else is refused by _forward: no CPU path)
+            model.ensure_packed(views[idx[0]]["image"].device)
     # Two shape groups in flight: the groups are independent, so they alternate between two side streams (each with its
     # own runner = its own workspaces) and fill each other's ramps and tails (a group of ~13 VGA images is a small
-    # batch for the chip).  Only with deferred counts -- no host synchronisation between the groups -- i.e. a finite
-    # max_num_keypoints; $GFC_SP_VIEW_STREAMS=0 keeps everything on the caller's stream.
+    # batch for the chip).  Only with deferred counts (a finite max_num_keypoints, no padding): otherwise every group
+    # ends in a host synchronisation and there is nothing to overlap.  $GFC_SP_VIEW_STREAMS=0 keeps everything on the
+    # caller's stream.
     lanes = None
-    if len(shared) > 1 and os.environ.get("GFC_SP_VIEW_STREAMS", "1") != "0":
+    if len(shared) > 1 and model.defers_counts() and os.environ.get("GFC_SP_VIEW_STREAMS", "1") != "0":
         dev0 = views[shared[0][0]]["image"].device
-        if dev0.type == "cuda":
+        if dev0.type == "cuda" and all(views[idx[0]]["image"].device == dev0 for idx in shared):
             lanes = getattr(model, "_view_lanes", None)
             if lanes is None or lanes[0][0].device != dev0:
                 lanes = [(torch.cuda.Stream(dev0), SuperPointRunner()) for _ in range(2)]

@@ -109,6 +109,12 @@ class DiskUnet(nn.Module):
                    for i in range(4)]
         return {"device": device, "layers": layers}
 
+    def ensure_packed(self, device):
+        """Packed filters for `device`, built on the calling thread's current stream if they do not exist yet."""
+        if self._packed is None or self._packed["device"] != device:
+            self._packed = self._pack(device)
+        return self._packed
+
     # ---- one Conv of the network: [statistics ->] convolution with normalisation + gate fused into its input stage ----
     def _conv(self, layer, x, b, h, w, y, ldy, gated, st):
         lib = nat.lib()
@@ -135,9 +141,7 @@ class DiskUnet(nn.Module):
             raise ValueError(f"DISK: image size {(H, W)} leaves one pixel at the coarsest level; InstanceNorm needs more than "
                              "1 spatial element")
         dev = images.device
-        if self._packed is None or self._packed["device"] != dev:
-            self._packed = self._pack(dev)
-        L = self._packed["layers"]
+        L = self.ensure_packed(dev)["layers"]
         lib, st = nat.lib(), nat.stream_ptr(dev)
         images = images.contiguous().float()
         new = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731

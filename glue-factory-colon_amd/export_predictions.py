@@ -14,10 +14,10 @@ MI355X additions.  The evaluation loop runs at batch 1 because the IMAGES of an 
   (LightGlue is image-size independent once the key points exist; gfc_lg_forward_ragged).  Records are those of the
   sequential loop (integers identical, floats within the batch-size dependence of the kernels' summation order) and
   are written in loader order.
-* `workers` > 1: that many host threads, each with its own HIP stream and its own replica of the model (own
-  workspaces; the weights are read-only), process different pairs -- or different pair batches -- at the same time.
+* `workers` > 1 (with pair_batch 1): that many host threads, each with its own HIP stream and its own launch state
+  (workspaces, side streams) around the SHARED read-only weights, process different pairs at the same time.  Not
+  combinable with `pair_batch` > 1 (a pair batch already fills the chip; measured slower together: DESIGN.md 6).
 """
-import copy
 import queue
 import threading
 from pathlib import Path
@@ -36,27 +36,36 @@ def _to_device(data, device):
     return data
 
 
+def _ensure_packed(model, device):
+    """Every module of `model` that keeps packed device weights builds them now, on the calling thread's stream."""
+    for m in model.modules():
+        if hasattr(m, "ensure_packed") and getattr(m, "are_weights_initialized", True):
+            m.ensure_packed(device)
+
+
 def _replicate(model):
-    """Independent copy of a model for another worker: own parameters, own workspaces; cached packed weights (raw
-    device pointers into the original's tensors) are dropped so that the copy packs its own on first use."""
-    # a model that has already run holds ctypes parameter structs in `_packed` (not copyable): set aside for the copy
-    stash = [(m, m._packed) for m in model.modules() if getattr(m, "_packed", None) is not None]
-    lanes = [(m, m._view_lanes) for m in model.modules() if getattr(m, "_view_lanes", None) is not None]
-    for m, _ in stash:
-        m._packed = None
-    for m, _ in lanes:  # side streams + runners of forward_views: per model instance, rebuilt by the copy on first use
-        m._view_lanes = None
-    try:
-        rep = copy.deepcopy(model)
-    finally:
-        for m, packed in stash:
-            m._packed = packed
-        for m, l in lanes:
-            m._view_lanes = l
-    for m in rep.modules():
-        if hasattr(m, "_packed"):
-            m._packed = None
-    return rep
+    """Another worker's view of `model`: the SAME parameters and the same packed device weights (read-only on the
+    path), its own launch state -- runners / workspaces, side streams, captured graphs.  Nothing is copied on the
+    device, so there is no copy whose completion a worker's stream would have to wait for; the caller packs the
+    weights (`_ensure_packed`) and makes the worker streams wait on its own stream before the workers start."""
+    from . import _native as nat
+    from ._superpoint_common import SuperPointRunner
+
+    def clone(m):
+        c = m.__class__.__new__(m.__class__)
+        c.__dict__ = dict(m.__dict__)
+        c._modules = type(m._modules)((k, None if v is None else clone(v)) for k, v in m._modules.items())
+        if "_runner" in c.__dict__:
+            c._runner = SuperPointRunner()
+        if "_ws" in c.__dict__:
+            c._ws = nat.Workspace()
+        if "_graphs" in c.__dict__:
+            c._graphs = {}
+        if "_view_lanes" in c.__dict__:
+            c._view_lanes = None
+        return c
+
+    return clone(model)
 
 
 def _process(model, data, keys, optional_keys, callback_fn, as_half):
@@ -198,7 +207,7 @@ def _gather_to_rank0(local, failed_here, rank, world, device):
     of bytes, padded to the largest block (the npz container inside keeps each pair's arrays with their own shapes
     and dtypes: an HPatches pair is ~40 KB, 540 pairs ~22 MB over 8 ranks).  A one-integer all-gather in front of it
     carries the block sizes and doubles as the failure flag (-1): a rank that failed must not leave the others
-    waiting in a collective.  Returns (entries on rank 0 / None elsewhere, any_rank_failed)."""
+    waiting in a collective.  Returns (the ranks' raw blocks on rank 0 / None elsewhere, any_rank_failed)."""
     import io
 
     import torch.distributed as dist
@@ -222,9 +231,16 @@ def _gather_to_rank0(local, failed_here, rank, world, device):
     dist.gather(block, out, dst=0)
     if rank != 0:
         return None, False
+    # raw blocks: decoded by the caller inside the try that feeds the closing failure flag
+    return [out[r][:sizes[r]].cpu().numpy().tobytes() for r in range(world)], False
+
+
+def _decode_blocks(blocks):
+    """[(index, name, record)] from the ranks' npz blocks."""
+    import io
     entries = []
-    for r in range(world):
-        with np.load(io.BytesIO(out[r][:sizes[r]].cpu().numpy().tobytes()), allow_pickle=False) as z:
+    for raw in blocks:
+        with np.load(io.BytesIO(raw), allow_pickle=False) as z:
             recs = {}
             for full in z.files:
                 head, key = full.rsplit("/", 1)
@@ -232,7 +248,7 @@ def _gather_to_rank0(local, failed_here, rank, world, device):
         for head, rec in recs.items():
             idx, name = head.split("|", 1)
             entries.append((int(idx), name, rec))
-    return entries, False
+    return entries
 
 
 @torch.no_grad()
@@ -263,7 +279,7 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
                          workers, local, pair_batch)
         except Exception as e:  # noqa: BLE001 -- re-raised below, after the other ranks have been told
             failure = e
-        entries, failed = _gather_to_rank0(local, failure is not None, rank, world, device)
+        blocks, failed = _gather_to_rank0(local, failure is not None, rank, world, device)
         if failed:
             if failure is not None:
                 raise failure
@@ -271,7 +287,7 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
         try:
             if rank == 0:  # records in loader order, first name wins (as the single-process loop)
                 records = {}
-                for _, name, rec in sorted(entries, key=lambda e: e[0]):
+                for _, name, rec in sorted(_decode_blocks(blocks), key=lambda e: e[0]):
                     if name not in records:
                         records[name] = rec
                 _write(output_file, records)
@@ -319,6 +335,9 @@ def _batches(indexed, n):
 def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out, pair_batch=1):
     """Process (index, item) pairs; appends (index, name, record) to `out`."""
     pair_batch = max(1, int(pair_batch or 1))
+    if workers > 1 and pair_batch > 1 and device != "cpu":
+        raise ValueError("export_predictions: workers > 1 and pair_batch > 1 are not combinable (a pair batch fills the "
+                         "chip by itself; use pair_batch alone)")
 
     def run_chunk(replica, chunk):
         """-> [(index, name, record)] of up to pair_batch consecutive items"""
@@ -348,13 +367,18 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
             out.extend(run_chunk(model, chunk))
         return
 
-    # ---- `workers` chunks in flight: one thread + one HIP stream + one model replica each ----
-    replicas = [model] + [_replicate(model) for _ in range(workers - 1)]
+    # ---- `workers` pairs in flight: one thread + one HIP stream + its own launch state each, shared weights ----
+    dev = torch.device("cuda", torch.cuda.current_device())
+    main = torch.cuda.current_stream(dev)
+    _ensure_packed(model, dev)  # on the caller's stream, which every worker stream waits on before its first launch
+    replicas = [_replicate(model) for _ in range(workers)]  # the model's own launch state stays with the caller's stream
+    streams = [torch.cuda.Stream(dev) for _ in replicas]
+    for st in streams:
+        st.wait_stream(main)
     tasks: "queue.Queue" = queue.Queue(maxsize=2 * workers)
     results, errors = [], []
 
-    def run(replica):
-        stream = torch.cuda.Stream(device)
+    def run(replica, stream):
         with torch.no_grad(), torch.cuda.stream(stream):
             while True:
                 chunk = tasks.get()
@@ -365,7 +389,7 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
                 except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
                     errors.append(e)
 
-    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in replicas]
+    threads = [threading.Thread(target=run, args=(r, st), daemon=True) for r, st in zip(replicas, streams)]
     for t in threads:
         t.start()
     for chunk in _batches(indexed, pair_batch):
@@ -376,6 +400,8 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
         tasks.put(None)
     for t in threads:
         t.join()
+    for st in streams:  # every record was copied to the host by its worker; the caller's stream continues after them
+        main.wait_stream(st)
     if errors:
         raise errors[0]
     out.extend(sorted(results, key=lambda e: e[0]))

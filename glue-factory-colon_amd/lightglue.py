@@ -230,12 +230,13 @@ class LightGlue(nn.Module):
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     run()
             e["graph"] = graph
-        except nat.NativeError:
-            raise  # an error status of gfc_lg_forward_packed is a real failure, never a reason to fall back
-        except RuntimeError as exc:  # the capture itself was refused (e.g. another thread is using the device)
+        except (nat.NativeError, RuntimeError) as exc:
+            # the capture was refused (another thread is using the device) or a launch failed UNDER capture: the same
+            # launch sequence once more outside any capture -- an error status there is a real failure and propagates
+            run()
             if not getattr(LightGlue, "_graph_fallback_logged", False):
                 LightGlue._graph_fallback_logged = True
-                print(f"glue_factory_colon_amd.lightglue: HIP graph capture refused ({exc}); problems of shape "
+                print(f"glue_factory_colon_amd.lightglue: HIP graph capture failed ({exc}); problems of shape "
                       f"{key[:3]} run with eager launches", file=sys.stderr)
             e = {"graph": None}
         self._graphs[key] = e
@@ -299,6 +300,16 @@ class LightGlue(nn.Module):
             p.token_w[i], p.token_b[i] = dev(tc.token[0].weight.reshape(-1)), dev(tc.token[0].bias)
         return p, keep, device
 
+    def ensure_packed(self, device):
+        """The device copies of the weights in the library's layouts, built on the CALLING thread's current stream if
+        they do not exist yet (export workers share them: the caller packs before its worker streams start)."""
+        if not self.are_weights_initialized:
+            raise RuntimeError("LightGlue weights are not loaded (conf.weights or load_state_dict)")
+        if self._packed is None or self._packed[2] != device:
+            self._packed = self._pack(device)
+            self._graphs = {}
+        return self._packed
+
     # -- forward ------------------------------------------------------------------------
     def forward(self, data: dict) -> dict:
         for key in self.required_data_keys:
@@ -337,9 +348,7 @@ class LightGlue(nn.Module):
             return self._forward_adaptive(kpts0, kpts1, desc0, desc1, size0, size1, so0, so1)
         d = conf.descriptor_dim
         if m > 0 and n > 0:
-            if self._packed is None or self._packed[2] != device:
-                self._packed = self._pack(device)
-                self._graphs = {}
+            self.ensure_packed(device)
             lib = nat.lib()
             s0 = torch.as_tensor(size0, device=device, dtype=torch.float32).expand(b, 2).contiguous()
             s1 = torch.as_tensor(size1, device=device, dtype=torch.float32).expand(b, 2).contiguous()
@@ -427,9 +436,7 @@ class LightGlue(nn.Module):
             raise RuntimeError("LightGlue weights are not loaded (conf.weights or load_state_dict)")
         device = items[0]["keypoints0"].device
         nat.require_cuda(items[0]["keypoints0"], "data['keypoints0']")
-        if self._packed is None or self._packed[2] != device:
-            self._packed = self._pack(device)
-            self._graphs = {}
+        self.ensure_packed(device)
         d, din = conf.descriptor_dim, conf.input_dim
         # equal shapes next to each other (stable): every run of equal (m, n) is one batched assignment head
         shapes = [(int(it["keypoints0"].shape[1]), int(it["keypoints1"].shape[1])) for it in items]
@@ -516,9 +523,7 @@ class LightGlue(nn.Module):
         n = kpts1.shape[1]
         assert b == 1
         device = kpts0.device
-        if self._packed is None or self._packed[2] != device:
-            self._packed = self._pack(device)
-        params = self._packed[0]
+        params = self.ensure_packed(device)[0]
         st = nat.stream_ptr(device)
         d = conf.descriptor_dim
         do_early_stop, do_prune = conf.depth_confidence > 0, conf.width_confidence > 0

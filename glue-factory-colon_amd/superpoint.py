@@ -88,6 +88,26 @@ class SuperPoint(BaseModel):
                                 cv(self.convPb), cv(self.convDb), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic", None))
 
+    def ensure_packed(self, device):
+        """The device copies of the weights in the library's layouts, built on the CALLING thread's current stream if
+        they do not exist yet (see superpoint_open.SuperPoint.ensure_packed)."""
+        if not self.are_weights_initialized:
+            raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
+        if self._packed is None or self._packed.device != device:
+            self._packed = self._pack(device)
+        return self._packed
+
+    def _max_keypoints(self):
+        max_kps = conf_get(self.conf, "max_num_keypoints")
+        if not self.training and conf_get(self.conf, "max_num_keypoints_val") is not None:
+            max_kps = conf_get(self.conf, "max_num_keypoints_val")
+        return None if (max_kps is None or max_kps <= 0) else int(max_kps)
+
+    def defers_counts(self):
+        """True when a per-image call can leave the key-point counts on the device (run_extractor, defer_counts)."""
+        return (bool(conf_get(self.conf, "sparse_outputs")) and self._max_keypoints() is not None
+                and not conf_get(self.conf, "force_num_keypoints"))
+
     def _forward(self, data, per_image=False, defer_counts=False, runner=None):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
@@ -96,19 +116,14 @@ class SuperPoint(BaseModel):
             raise NotImplementedError("training-time multinomial sampling is out of scope (inference path)")
         specular = "after_topk" if ("specular_mask" in data and conf_get(conf, "filter_specular_keypoints")) else None
         nat.require_cuda(data["image"], "data['image']")
-        device = data["image"].device
-        if self._packed is None or self._packed.device != device:
-            self._packed = self._pack(device)
+        self.ensure_packed(data["image"].device)
         if not conf_get(conf, "sparse_outputs"):
             with torch.no_grad():
                 image = data["image"].float().contiguous()
                 heat, desc_raw = self._runner.dense(self._packed, image)
                 dense = self._runner.l2norm_rows(desc_raw)
             return {"keypoint_scores": heat, "descriptors": dense.permute(0, 3, 1, 2)}
-        max_kps = conf_get(conf, "max_num_keypoints")
-        if not self.training and conf_get(conf, "max_num_keypoints_val") is not None:
-            max_kps = conf_get(conf, "max_num_keypoints_val")
-        k = None if (max_kps is None or max_kps <= 0) else int(max_kps)
+        k = self._max_keypoints()
         with torch.no_grad():
             return run_extractor(
                 runner or self._runner, self._packed, data,

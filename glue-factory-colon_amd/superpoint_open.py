@@ -101,14 +101,27 @@ class SuperPoint(BaseModel):
                                 blk(self.descriptor[1]), device,
                                 conv_mode=conf_get(self.conf, "conv_arithmetic"))
 
+    def ensure_packed(self, device):
+        """The device copies of the weights in the library's layouts, built on the CALLING thread's current stream if
+        they do not exist yet.  Whoever hands this module to another stream (extract_views' lanes, export workers)
+        calls this first on the stream the others wait on: packing is a sequence of kernels like any other."""
+        if not self.are_weights_initialized:
+            raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
+        if self._packed is None or self._packed.device != device:
+            self._packed = self._pack(device)
+        return self._packed
+
+    def defers_counts(self):
+        """True when a per-image call can leave the key-point counts on the device (run_extractor, defer_counts)."""
+        k = conf_get(self.conf, "max_num_keypoints")
+        return k is not None and not conf_get(self.conf, "force_num_keypoints")
+
     def _forward(self, data, per_image=False, defer_counts=False, runner=None):
         if not self.are_weights_initialized:
             raise RuntimeError("SuperPoint weights are not loaded (conf.weights or load_state_dict)")
         specular = "before_topk" if ("specular_mask" in data and conf_get(self.conf, "filter_specular_keypoints")) else None
         nat.require_cuda(data["image"], "data['image']")
-        device = data["image"].device
-        if self._packed is None or self._packed.device != device:
-            self._packed = self._pack(device)
+        self.ensure_packed(data["image"].device)
         with torch.no_grad():
             return run_extractor(
                 runner or self._runner, self._packed, data,

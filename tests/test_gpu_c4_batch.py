@@ -5,7 +5,7 @@ GPUs), through extractor and matcher exactly as `bench.py --workload c4` does (b
 Only at this batch does the library dispatch the kernel variants that workload is timed on: `attention_kernel<2,4>` on
 2048 x 2048 problems (64 problems x 4 heads x 8 query blocks), the 128 x 128 GEMM tile and the row-owning FFN GEMM on
 131072 rows, the two-sweep assignment tail on a [32, 2049, 2049] matrix (537 MB).  Checked here:
-  * 2 of the 32 pairs against the CPU oracle (reference path restated, oracle/): key-point sets (0 unexplained flips),
+  * 9 of the 32 pairs against the CPU oracle (reference path restated, oracle/): key-point sets (0 unexplained flips),
     matched coordinate pairs, scores <= 1e-4;
   * batch invariance: all 32 pairs identical on every integer output (key points, matches0/1) -- and within 1e-4 on
     the scores -- to the same pairs run 2 at a time (other GEMM tile, attention_kernel<1,4>).
@@ -23,7 +23,7 @@ from parity_utils import compare_keypoints, match_pairs, record  # noqa: E402
 
 DEV = "cuda"
 H, W, K, B = 1024, 1024, 2048, 32
-ORACLE_PAIRS = (3, 29)
+ORACLE_PAIRS = (0, 3, 7, 12, 16, 21, 26, 29, 31)
 
 
 def run_batch(ext, mat, v0, v1):
@@ -56,7 +56,7 @@ def test_c4_batch32_vs_oracle(c4_batch32):
     v0, v1, _, _, p0, p1, out = c4_batch32
     sd_sp, sd_lg = weights.superpoint_open_state_dict(0), weights.lightglue_state_dict(0)
     size = torch.tensor([[float(W), float(H)]])
-    n_ref_total = n_same = 0
+    n_ref_total = n_same = n_elementwise = 0
     worst = 0.0
     for i in ORACLE_PAIRS:
         imgs = torch.cat([v0[i:i + 1], v1[i:i + 1]], 0).cpu()
@@ -83,7 +83,13 @@ def test_c4_batch32_vs_oracle(c4_batch32):
         err = max(abs(sm[q] - sr[q]) for q in set(sm) & set(sr))
         worst = max(worst, err)
         assert err < 1e-4, (i, err)  # north star: scores within 1e-4 fp32
-    record("c4_batch32_vs_oracle", pairs=len(ORACLE_PAIRS), ref_matches=n_ref_total, identical=n_same, score_err=worst)
+        if torch.equal(p0["keypoints"][i].cpu(), okp[0]) and torch.equal(p1["keypoints"][i].cpu(), okp[1]):
+            # no near-tie rank swap in either view: the arrays themselves are the oracle's, index by index
+            assert torch.equal(out["matches0"][i].cpu(), ref["matches0"][0]), i
+            assert torch.equal(out["matches1"][i].cpu(), ref["matches1"][0]), i
+            n_elementwise += 1
+    record("c4_batch32_vs_oracle", pairs=len(ORACLE_PAIRS), ref_matches=n_ref_total, identical=n_same, score_err=worst,
+           pairs_with_elementwise_identical_arrays=n_elementwise)
 
 
 def test_c4_batch32_batch_invariance(c4_batch32):

@@ -452,3 +452,27 @@ def test_disk_network_state_dict_layout_and_checkpoint_file(tmp_path):
     assert out[0].shape == (1, 1, 32, 48) and out[1].shape == (1, 128, 32, 48)
     with pytest.raises(ValueError, match="divisible by 16"):
         ounet.unet(sd, torch.rand(1, 3, 30, 48))
+
+
+def test_worker_replicas_share_weights_and_own_their_launch_state():
+    """export_predictions(workers > 1): a replica is another view of the SAME parameters (nothing copied, so nothing to
+    synchronise) with its own runners / workspaces / side streams; the module tree is cloned, not shared."""
+    from glue_factory_colon_amd import export_predictions as ep
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+    pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", "weights": "synthetic",
+                                          "max_num_keypoints": 64},
+                            "matcher": {"name": "matchers.lightglue_pretrained", "weights": "synthetic"}}).eval()
+    rep = ep._replicate(pipe)
+    assert rep is not pipe and rep.extractor is not pipe.extractor and rep.matcher.net is not pipe.matcher.net
+    for (n0, p0), (n1, p1) in zip(pipe.named_parameters(), rep.named_parameters()):
+        assert n0 == n1 and p0 is p1
+    assert rep.extractor._runner is not pipe.extractor._runner
+    assert rep.matcher.net._ws is not pipe.matcher.net._ws
+    assert rep.matcher.net._graphs is not pipe.matcher.net._graphs
+    assert rep.extractor._packed is pipe.extractor._packed  # (None here: no GPU; shared once packed)
+    assert rep.extractor.conf is pipe.extractor.conf and not rep.training
+    # the combination that round 5 removed is refused before any GPU work
+    import pytest as _pytest
+    with _pytest.raises(ValueError, match="not combinable"):
+        ep._export_loop(iter(()), pipe, "cuda", "*", [], None, False, 2, [], 2)
