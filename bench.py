@@ -186,7 +186,7 @@ def batch1_latency(dev, n_pairs: int = 24, warmup: int = 4):
 
 
 
-def c3_regime(dev, n_pairs: int = 128):
+def c3_regime(dev, n_pairs: int = 128, n_host: int = 64):
     """Information only (never `value`): BASELINE config 3's regime -- the HPatches evaluation loop
     (utils/export_predictions.py:36-85: batch 1 because the IMAGES differ in size; official SuperPoint + LightGlue,
     1024 key points, detection threshold 0) on an HPatches-shaped list of mixed image shapes, through this package's
@@ -209,9 +209,10 @@ def c3_regime(dev, n_pairs: int = 128):
                         "depth_confidence": -1, "width_confidence": -1, "filter_threshold": 0.1},
             "profile_calls": profiled}).eval().to(dev)
 
-    def run(pipe, workers, pair_batch):
+    def run(pipe, workers, pair_batch, source=None):
         out = []
-        ep._export_loop(enumerate(items), pipe, "cuda", keys, optional, None, False, workers, out, pair_batch)
+        ep._export_loop(enumerate(items if source is None else source), pipe, "cuda", keys, optional, None, False,
+                        workers, out, pair_batch)
         return out
 
     def compare(out, base):
@@ -270,6 +271,36 @@ def c3_regime(dev, n_pairs: int = 128):
             **compare(sorted(fresh, key=lambda e: e[0]), base)}
         legs["pair_batch32_first_call_of_fresh_pipeline"]["integers_equal_to_first_leg"] = \
             legs["pair_batch32_first_call_of_fresh_pipeline"]["pairs_differing"] == 0
+        # the loop that FEEDS the path (datasets/hpatches.py:94-112 + utils/image.py:33-72): decoded uint8 images in
+        # pinned host memory -> async H2D on a copy stream -> gfc_preprocess_resize (short side 480, antialias) ->
+        # forward_pairs(32) -> records; beside it the same images already preprocessed and resident in HBM
+        from glue_factory_colon_amd.image_preprocessor import HostImageFeeder
+        raw = synthetic.hpatches_like_host_images(n_host)
+        pconf = {"resize": 480, "side": "short"}
+        host = {}
+        for tag in ("from_host_uint8_pair_batch32", "resident_same_images_pair_batch32"):
+            best, feeder = None, None
+            resident = list(HostImageFeeder(raw, pconf)) if tag.startswith("resident") else None
+            for rep in range(3):  # first pass untimed
+                feeder = HostImageFeeder(raw, pconf) if resident is None else None
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                out = run(pipe, 1, 32, feeder if resident is None else resident)
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+                if rep:
+                    best = dt if best is None else min(best, dt)
+            host[tag] = {"pairs_per_s": round(n_host / best, 1),
+                         "matches_total": sum(int((rec["matches0"] >= 0).sum()) for _, _, rec in out)}
+            if feeder is not None:
+                host[tag]["h2d_mb_per_pair"] = round(feeder.h2d_bytes / n_host / 1e6, 2)
+        host["same_integers"] = host["from_host_uint8_pair_batch32"]["matches_total"] == \
+            host["resident_same_images_pair_batch32"]["matches_total"]
+        host["sample"] = (f"{n_host} pairs of decoded RGB uint8 images at original sizes "
+                          f"{synthetic.HPATCHES_LIKE_ORIGINALS} (pinned host memory), ImagePreprocessor resize 480 / side "
+                          "short on the GPU (HostImageFeeder), then the pair_batch32 export loop; `resident_*` = the "
+                          "same preprocessed images already in HBM")
+        res["from_host_uint8"] = host
     res["same_match_count"] = len({v["matches_total"] for v in legs.values()}) == 1
     res["all_legs_integers_equal"] = all(v["integers_equal_to_first_leg"] for v in legs.values())
     res["legs"] = legs

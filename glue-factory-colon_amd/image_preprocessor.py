@@ -3,8 +3,14 @@ configuration keys, same returned dict (`image`, `scales`, `image_size`, `transf
 square padding and `padding_mask`).  The resize itself -- kornia's antialiased bilinear resize in the reference -- runs
 in `gfc_preprocess_resize`; it also accepts the decoded uint8 HxWxC image directly, fusing `numpy_image_to_torch`
 (image.py:148-156).  Decoding files (cv2.imread) stays on the host and is not part of this module.
+
+`HostImageFeeder` is the loader-side counterpart for the evaluation loop (datasets/hpatches.py:94-112 reads and
+preprocesses both images of a pair on CPU worker processes, export_predictions.py:36-37 then copies the float images to
+the device): decoded uint8 images in pinned host memory -> asynchronous host-to-device copies on a copy stream ->
+`gfc_preprocess_resize` on the consumer's stream -> the loader item the export loop expects, tensors on the GPU.
 """
 import collections.abc as collections
+from collections import deque
 
 import numpy as np
 import torch
@@ -111,3 +117,90 @@ class ImagePreprocessor:
         if step is not None:
             size = [int(v // step * step) for v in size]
         return size
+
+
+class HostImageFeeder:
+    """Iterable of loader items for `export_predictions` fed from DECODED uint8 images on the host.
+
+    raw_items: sequence of dicts like the HPatches dataset's items before preprocessing: `{"name": str, "view0":
+    {"image": uint8 [H,W,3] / [H,W] host tensor (RGB; pinned memory makes its copy asynchronous)}, "view1": {...},
+    ...other keys passed through}`.  Per item and view the work of `HPatches._read_image` after decoding
+    (numpy_image_to_torch + ImagePreprocessor, image.py:33-72,148-156) happens on the GPU: the bytes travel on a copy
+    stream, `depth` items ahead of the consumer; the fused conversion + antialiased resize runs on the consumer's stream
+    behind the copy's event; `scales` / `image_size` / `original_image_size` (host arithmetic) follow in one small
+    pinned copy per item.  No host synchronisation anywhere: the export loop's kernels and the next items' copies overlap.
+    Yields batch-1 items (`image` [1,C,h,w] float32, `scales` [1,2], `image_size` [1,2], `original_image_size` [1,2],
+    `transform` [1,3,3] float64 on the host), i.e. what the reference's DataLoader collates."""
+
+    def __init__(self, raw_items, conf, device="cuda", depth=64, bgr=False):
+        self.raw, self.pre, self.depth, self.bgr = raw_items, ImagePreprocessor(conf), max(1, int(depth)), bool(bgr)
+        if self.pre.conf["square_pad"]:
+            raise NotImplementedError("square_pad on the host-image path")
+        if self.pre.conf["interpolation"] != "bilinear":
+            raise NotImplementedError("only 'bilinear' is built on the GPU path")
+        self.device = torch.device(device if device != "cuda" else f"cuda:{torch.cuda.current_device()}")
+        self.h2d_bytes = 0
+
+    def __len__(self):
+        return len(self.raw)
+
+    def _stage(self, raw, copy_stream):
+        """Issue the copies of one item on the copy stream; returns what `_finish` needs."""
+        views, meta = {}, []
+        for tag in ("view0", "view1"):
+            u8 = raw[tag]["image"]
+            if u8.dtype != torch.uint8 or u8.ndim not in (2, 3):
+                raise ValueError(f"{tag}: expected a decoded uint8 image [H,W,C] or [H,W], got {u8.dtype} {tuple(u8.shape)}")
+            h, w = int(u8.shape[0]), int(u8.shape[1])
+            size = (h, w) if self.pre.conf["resize"] is None else tuple(self.pre.get_new_image_size(h, w))
+            # torch.Tensor([new_w / w, new_h / h]) (image.py:49): python floats rounded to fp32
+            meta += [size[1] / w, size[0] / h, float(size[1]), float(size[0]), float(w), float(h)]
+            with torch.cuda.stream(copy_stream):
+                dev = u8.to(self.device, non_blocking=True)
+            self.h2d_bytes += u8.numel()
+            views[tag] = (dev, size, (h, w))
+        host_meta = torch.tensor(meta, dtype=torch.float32).pin_memory()
+        with torch.cuda.stream(copy_stream):
+            dev_meta = host_meta.to(self.device, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy_stream)
+        return raw, views, dev_meta, host_meta, done
+
+    def _finish(self, staged):
+        raw, views, dev_meta, host_meta, done = staged
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(done)
+        dev_meta.record_stream(main)
+        item = {k: v for k, v in raw.items() if k not in ("view0", "view1")}
+        if isinstance(item.get("name"), str):
+            item["name"] = [item["name"]]  # as collated by the DataLoader
+        for j, tag in enumerate(("view0", "view1")):
+            dev, size, (h, w) = views[tag]
+            dev.record_stream(main)
+            conf = self.pre.conf
+            if conf["resize"] is not None:
+                img = resize(dev, size, conf["align_corners"], conf["antialias"], bgr=self.bgr)
+            else:
+                img = resize(dev, size, None, False, bgr=self.bgr)  # conversion only
+            m = dev_meta[6 * j: 6 * j + 6]
+            sx, sy = size[1] / w, size[0] / h
+            extra = {k: v for k, v in raw[tag].items() if k != "image"}
+            item[tag] = {**extra, "image": img[None], "scales": m[0:2][None], "image_size": m[2:4][None],
+                         "original_image_size": m[4:6][None],
+                         "transform": torch.from_numpy(np.diag([np.float32(sx), np.float32(sy), 1.0]))[None]}
+        return item
+
+    def __iter__(self):
+        copy_stream = torch.cuda.Stream(self.device)
+        pending = deque()
+        it = iter(self.raw)
+        exhausted = False
+        while True:
+            while not exhausted and len(pending) < self.depth:
+                try:
+                    pending.append(self._stage(next(it), copy_stream))
+                except StopIteration:
+                    exhausted = True
+            if not pending:
+                return
+            yield self._finish(pending.popleft())

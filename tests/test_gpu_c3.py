@@ -219,6 +219,57 @@ def test_first_call_of_a_fresh_pipeline_is_the_pair_batched_export(tmp_path, thr
            float_err_pair_batch=ferr, float_err_workers=ferr2)
 
 
+def test_export_from_host_uint8_images_with_gpu_preprocessing(tmp_path):
+    """The loop that FEEDS the path (datasets/hpatches.py:94-112 + utils/image.py:33-72 -> export_predictions.py:36-45):
+    decoded uint8 images in pinned host memory -> asynchronous H2D copies -> gfc_preprocess_resize (short side 480,
+    antialias) -> forward_pairs(pair_batch=32) -> records un-scaled by 1/scales, against the sequential loop fed by the
+    CPU preprocessing of oracle/preprocess.py (numpy_image_to_torch + ImagePreprocessor restated; kornia's resize is
+    absent offline: that half is unpinned) on the same bytes.  Integers identical, floats within 1e-4 (key points
+    are in ORIGINAL-image pixels, |x| up to 1280: 1e-3 there)."""
+    from glue_factory_colon_amd import synthetic
+    from glue_factory_colon_amd.image_preprocessor import HostImageFeeder
+    from oracle import preprocess as opre
+
+    raw = synthetic.hpatches_like_host_images(40, seed=5000)
+    keys = EXPORT_KEYS + ["keypoint_scores0", "keypoint_scores1"]
+    conf = {"resize": 480, "side": "short"}
+    cpu_items = []
+    for it in raw:
+        item = {"name": [it["name"]]}
+        for v in ("view0", "view1"):
+            d = opre.preprocess(opre.numpy_image_to_torch(it[v]["image"].numpy()), resize=480, side="short")
+            item[v] = {"image": d["image"][None], "scales": d["scales"][None],
+                       "image_size": torch.from_numpy(d["image_size"])[None].float()}
+        cpu_items.append(item)
+    assert len({tuple(i[v]["image"].shape[-2:]) for i in cpu_items for v in ("view0", "view1")}) == 5
+    seq = load_predictions(export_predictions(cpu_items, official_pipeline(), tmp_path / "seq.npz", keys=keys))
+    feeder = HostImageFeeder(raw, conf)
+    bat = load_predictions(export_predictions(feeder, official_pipeline(), tmp_path / "bat.npz", keys=keys, pair_batch=32))
+    assert list(seq) == list(bat) and len(seq) == 40
+    assert feeder.h2d_bytes == sum(it[v]["image"].numel() for it in raw for v in ("view0", "view1"))
+    ferr = kerr = 0.0
+    total = 0
+    for name in seq:
+        a, b = seq[name], bat[name]
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, (name, k)
+            if a[k].dtype.kind in "iu":
+                assert (a[k] == b[k]).all(), (name, k, int((a[k] != b[k]).sum()))
+            elif k.startswith("keypoints"):
+                kerr = max(kerr, float(np.abs(a[k] - b[k]).max()))
+            else:
+                ferr = max(ferr, float(np.abs(a[k] - b[k]).max()))
+        total += int((a["matches0"] >= 0).sum())
+    assert ferr < 1e-4 and kerr < 1e-3, (ferr, kerr)
+    assert total > 40 * 100
+    # the same feeder items consumed pair by pair (resident tensors, no batching): identical integers again
+    one = load_predictions(export_predictions(list(HostImageFeeder(raw, conf)), official_pipeline(), tmp_path / "one.npz",
+                                              keys=keys))
+    _assert_records_equal(one, bat, 40)
+    record("c3_from_host_uint8_pb32_vs_cpu_preprocessed_sequential", pairs=40, matches_total=total, float_err=ferr,
+           keypoint_err_px=kerr, h2d_mb_per_pair=feeder.h2d_bytes / 40 / 1e6)
+
+
 def test_workers_and_pair_batch_are_not_combinable(tmp_path):
     """Round-5 pruning: `workers` > 1 together with `pair_batch` > 1 is refused (slower than pair_batch alone)."""
     items = hpatches_shaped_list(4)

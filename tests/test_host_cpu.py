@@ -476,3 +476,79 @@ def test_worker_replicas_share_weights_and_own_their_launch_state():
     import pytest as _pytest
     with _pytest.raises(ValueError, match="not combinable"):
         ep._export_loop(iter(()), pipe, "cuda", "*", [], None, False, 2, [], 2)
+
+
+def test_bench_multiprocess_plumbing_rehearsal_world8():
+    """The first 8-GPU run must not also be the first 8-rank run: bench.py --gpus 8 launched as the driver launches it,
+    with --rehearse-cpu (gloo): rendezvous on 127.0.0.1, barriers, MAX all-reduce, the final gather of 8 x 32 records."""
+    import json
+
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+           "127.0.0.1", "--master-port", _free_port(), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3",
+           "--warmup", "1", "--pairs", "32", "--rehearse-cpu", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stdout + r.stderr
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["pairs_gathered"] == 256  # BASELINE configs[3]: 256 pairs over 8 GPUs
+    assert out["matches_per_rank"] == [10 + r for r in range(8)]
+
+
+def test_export_predictions_sharded_world8_gloo_540_items(tmp_path):
+    """The HPatches list's size (540 pairs: 108 sequences x 5) shared out over 8 ranks on gloo: every item is processed
+    by exactly one rank (round-robin: rank r gets items r, r + 8, ...), rank 0 writes the records in LOADER order, and a
+    second export in which rank 5 fails leaves every rank with an exception and no file."""
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os, torch, numpy as np\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from glue_factory_colon_amd import sharding\n"
+        "from glue_factory_colon_amd.export_predictions import export_predictions, load_predictions\n"
+        "rank, world, _ = sharding.init_from_env('gloo')\n"
+        "seen = []\n"
+        "class Fake(torch.nn.Module):\n"
+        "    fail = False\n"
+        "    def forward(self, data):\n"
+        "        seen.append(int(data['idx']))\n"
+        "        if self.fail and rank == 5 and len(seen) == 3:\n"
+        "            raise ValueError('boom on rank 5')\n"
+        "        k0 = data['view0']['x'] + rank * 0  # the result does not depend on the rank that computes it\n"
+        "        return {'keypoints0': k0, 'matches0': (k0[..., 0] > 4).long() - 1, 'who': torch.full((1, 1), float(rank))}\n"
+        "def item(i):\n"
+        "    g = torch.Generator().manual_seed(i)\n"
+        "    n = 3 + i % 4\n"
+        "    return {'name': [f'seq{i // 5:03d}/{i % 5 + 2}.ppm'], 'idx': i,\n"
+        "            'view0': {'x': torch.rand((1, n, 2), generator=g) * 9, 'scales': torch.tensor([[0.5 + 0.001 * i, 0.75]])}}\n"
+        "items = [item(i) for i in range(540)]\n"
+        "out = sys.argv[1]\n"
+        "export_predictions(items, Fake(), out + '/p.npz', keys=['keypoints0', 'matches0', 'who'], pair_batch=4)\n"
+        "assert seen == list(range(rank, 540, world)), (rank, seen[:5])\n"
+        "if rank == 0:\n"
+        "    a = load_predictions(out + '/p.npz')\n"
+        "    assert list(a) == [it['name'][0] for it in items]\n"
+        "    for i, it in enumerate(items):\n"
+        "        r = a[it['name'][0]]\n"
+        "        assert int(r['who'][0]) == i % world\n"
+        "        assert np.array_equal(r['keypoints0'], (it['view0']['x'][0] * (1.0 / it['view0']['scales'])).numpy())\n"
+        "    print('WORLD8_EXPORT_OK')\n"
+        "torch.distributed.barrier()\n"
+        "seen.clear(); Fake.fail = True\n"
+        "try:\n"
+        "    export_predictions(items, Fake(), out + '/q.npz', keys=['keypoints0'])\n"
+        "    msg = 'NO_EXCEPTION'\n"
+        "except ValueError as e:\n"
+        "    msg = f'OWN {e}'\n"
+        "except RuntimeError as e:\n"
+        "    msg = f'TOLD {e}'\n"
+        "open(out + f'/rank{rank}.txt', 'w').write(msg)\n"
+        "assert not os.path.exists(out + '/q.npz')\n"
+        "torch.distributed.barrier()\n")
+    port = _free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script), str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "WORLD8_EXPORT_OK" in r.stdout, r.stdout + r.stderr
+    said = [(tmp_path / f"rank{i}.txt").read_text() for i in range(8)]
+    assert said[5] == "OWN boom on rank 5", said
+    assert all(s.startswith("TOLD") and "another rank failed" in s for i, s in enumerate(said) if i != 5), said
