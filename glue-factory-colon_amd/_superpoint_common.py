@@ -301,10 +301,9 @@ def extract_views(model, views):
     # Two shape groups in flight: the groups are independent, so they alternate between two side streams (each with its
     # own runner = its own workspaces) and fill each other's ramps and tails (a group of ~13 VGA images is a small
     # batch for the chip).  Only with deferred counts (a finite max_num_keypoints, no padding): otherwise every group
-    # ends in a host synchronisation and there is nothing to overlap.  $GFC_SP_VIEW_STREAMS=0 keeps everything on the
-    # caller's stream.
+    # ends in a host synchronisation and there is nothing to overlap.
     lanes = None
-    if len(shared) > 1 and model.defers_counts() and os.environ.get("GFC_SP_VIEW_STREAMS", "1") != "0":
+    if len(shared) > 1 and model.defers_counts():
         dev0 = views[shared[0][0]]["image"].device
         if dev0.type == "cuda" and all(views[idx[0]]["image"].device == dev0 for idx in shared):
             lanes = getattr(model, "_view_lanes", None)
@@ -406,8 +405,7 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
     smask = smask_wh = None
     if specular is not None:
         smask, smask_wh = specular_mask_bytes(data, b, image.device)
-    if (specular != "before_topk" and k is not None and 0 < k <= 8192 and nms_radius >= 1
-            and os.environ.get("GFC_SP_FUSED_SELECT", "1") != "0"):
+    if specular != "before_topk" and k is not None and 0 < k <= 8192 and nms_radius >= 1:
         kpts, ksc, counts = runner.nms_select(heat, nms_radius, remove_borders or 0, valid_wh, detection_threshold, k)
         core_time_ms = (time.perf_counter() - core_start) * 1e3  # like the reference: no device sync
     else:  # unlimited number of key points: dense suppressed map + ordered scan

@@ -330,12 +330,11 @@ extern "C" int gfc_attention(const float* Q, int ldq, const float* K, int ldk, c
   const int4* pt = reinterpret_cast<const int4*>(problems);
   // key split for small problem sets (batch 1..2): few 128-query blocks cannot fill 1024 SIMDs, so each block's
   // keys are shared out over up to 8 workgroups and a tiny merge kernel combines the partial soft-maxes
-  const int forced_split = gfc_knobs().attn_split;
   const int xcd = gfc_knobs().xcd_remap != 0;
   int ksplit = 1;
   if (cfg == 2 && ws != nullptr) {
     const long long w = wgs(128);
-    int want = forced_split ? forced_split : (w >= 256 ? 1 : (int)((511 + w) / w));
+    int want = w >= 256 ? 1 : (int)((511 + w) / w);
     if (want > 8) want = 8;
     while (want > 1 && ws_bytes < (size_t)n_problems * heads * max_nq * want * 66 * sizeof(float)) --want;
     ksplit = want < 1 ? 1 : want;

@@ -240,8 +240,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   const int o2 = (R2 * WP_C + tx) * WKC + ((h ^ (R2 & 3)) << 2);
 
 #if WINO_DIAG & 256
-  unsigned long long d_k = 0, d_x = 0, d_s = 0, d_n = 0;
+  unsigned long long d_k = 0, d_x = 0, d_s = 0, d_n = 0, d_epi10 = 0;
   const unsigned long long d_t0 = __builtin_readcyclecounter();
+#endif
+#ifdef WINO_STAGGER  // experiment (tools/ab_build.sh ... "-DWINO_STAGGER=1|2"): the two persistent workgroups of a CU start
+  // together and walk items of equal length, so their exchange epilogues coincide; half of the workgroups wait about half
+  // an item before their first one.  1: the upper half of the grid waits, 2: the odd workgroups wait.
+  if constexpr (!STEM) {
+    const bool late = WINO_STAGGER == 1 ? (blockIdx.x >= gridDim.x / 2) : (blockIdx.x & 1);
+    if (late && gridDim.x < (unsigned)nitems) {
+      const int n_sleep = cin <= 64 ? 3 : 5;
+      for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+  }
 #endif
   while (true) {
   WINO_T(t_a);
@@ -398,6 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   {
     WINO_T(t_d);
     d_k += t_b - t_a; d_x += t_c - t_b; d_s += t_d - t_c; d_n += 1;
+    if (d_n == 10) d_epi10 = t_b;  // absolute start of the 10th item's epilogue (phase of co-resident workgroups)
   }
 #endif
   if (!more) break;
@@ -406,10 +418,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   }  // persistent loop over work items
 #if WINO_DIAG & 256
   if (a.diag && lane == 0) {
-    unsigned hw;
+    unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     unsigned long long* o = a.diag + ((size_t)blockIdx.x * 4 + xi) * 8;
-    o[0] = d_k; o[1] = d_x; o[2] = d_s; o[3] = d_n; o[4] = __builtin_readcyclecounter() - d_t0; o[5] = hw; o[6] = d_t0;
+    o[0] = d_k; o[1] = d_x; o[2] = d_s; o[3] = d_n; o[4] = __builtin_readcyclecounter() - d_t0;
+    o[5] = (unsigned long long)hw | ((unsigned long long)(xcc & 0xf) << 32); o[6] = d_t0; o[7] = d_epi10;
   }
 #endif
 #undef WINO_DECODE

@@ -18,12 +18,14 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
   return i;
 }
 
+// One source value.  U8: interleaved HWC bytes through a 256-entry table of (float)((double)v / 255.0) -- value / 255 in
+// double, rounded once, as numpy_image_to_torch does -- built once per workgroup in LDS.
 template <bool U8>
-__device__ __forceinline__ float load_px(const void* src, int H, int W, int C, int c, int y, int x, int bgr) {
-  if (U8) {  // interleaved HWC bytes, value / 255 in double then rounded once (numpy_image_to_torch)
+__device__ __forceinline__ float load_px(const void* src, const float* lut, int H, int W, int C, int c, int y, int x, int bgr) {
+  if (U8) {
     const unsigned char* s = static_cast<const unsigned char*>(src);
     const int cc = bgr ? (C - 1 - c) : c;
-    return (float)((double)s[((size_t)y * W + x) * C + cc] / 255.0);
+    return lut[s[((size_t)y * W + x) * C + cc]];
   }
   return static_cast<const float*>(src)[((size_t)c * H + y) * W + x];  // planar CHW float
 }
@@ -34,7 +36,9 @@ __global__ __launch_bounds__(256) void resize_kernel(const void* __restrict__ sr
                                                      int ksy, int ksx, float sgy, float sgx, long long src_stride,
                                                      long long dst_stride) {
   __shared__ float wy[PP_MAX_KS], wx[PP_MAX_KS];
+  __shared__ float lut[256];
   const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+  if (U8) lut[tid] = (float)((double)tid / 255.0);
   if (ksy > 0) {
     // kornia gaussian(): x = arange(ks) - ks//2 (ks is odd here), exp(-x^2 / (2 sigma^2)), normalised
     if (tid < ksy) { const float d = (float)(tid - ksy / 2); wy[tid] = expf(-(d * d) / (2.f * sgy * sgy)); }
@@ -46,8 +50,8 @@ __global__ __launch_bounds__(256) void resize_kernel(const void* __restrict__ sr
     __syncthreads();
     if (tid < ksy) wy[tid] = wy[tid] / sy;
     if (tid >= 64 && tid < 64 + ksx) wx[tid - 64] = wx[tid - 64] / sx;
-    __syncthreads();
   }
+  __syncthreads();
   const int ox = blockIdx.x * blockDim.x + threadIdx.x, oy = blockIdx.y * blockDim.y + threadIdx.y;
   if (ox >= OW || oy >= OH) return;
   const char* sb = static_cast<const char*>(src) + (size_t)blockIdx.z * src_stride;
@@ -67,24 +71,34 @@ __global__ __launch_bounds__(256) void resize_kernel(const void* __restrict__ sr
   for (int c = 0; c < C; ++c) {
     float v00, v01, v10, v11;
     if (ksy > 0) {
+      // The blurred image at the four bilinear taps.  Each tap is sum_i wy[i] * (sum_j wx[j] * px) in that order (the
+      // separable filter of the restatement: horizontal pass, then vertical); the horizontal sums of a source row at
+      // x0 and x1 serve both vertical taps, so every source row of the (ksy + 1) x (ksx + 1) window is read once.
       const int ry = ksy / 2, rx = ksx / 2;
-      float t[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int cy = (q & 2) ? y1 : y0, cx = (q & 1) ? x1 : x0;
-        float acc = 0.f;
-        for (int i = 0; i < ksy; ++i) {
-          const int yy = reflect_idx(cy + i - ry, H);
-          float row = 0.f;
-          for (int j = 0; j < ksx; ++j) row += wx[j] * load_px<U8>(sb, H, W, C, c, yy, reflect_idx(cx + j - rx, W), bgr);
-          acc += wy[i] * row;
+      float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+      const bool two_y = y1 != y0, two_x = x1 != x0;
+      for (int i = 0; i <= ksy; ++i) {           // window row i <-> source row y0 - ry + i (before reflection)
+        if (i == ksy && !two_y) break;
+        // row y0 - ry + i is tap i of (y0, .) and tap i - 1 of (y1, .) when y1 = y0 + 1.  Reflection must be applied
+        // per (tap centre, offset) as the padded image defines it: reflect(cy + i' - ry) -- for y1 = y0 + 1 the two
+        // expressions name the same un-reflected row, hence the same reflected row.
+        const int yy = reflect_idx(y0 - ry + i, H);
+        float r0 = 0.f, r1 = 0.f;
+        for (int j = 0; j <= ksx; ++j) {
+          if (j == ksx && !two_x) break;
+          const float px = load_px<U8>(sb, lut, H, W, C, c, yy, reflect_idx(x0 - rx + j, W), bgr);
+          if (j < ksx) r0 += wx[j] * px;
+          if (two_x && j > 0) r1 += wx[j - 1] * px;
         }
-        t[q] = acc;
+        if (!two_x) r1 = r0;
+        if (i < ksy) { a00 += wy[i] * r0; a01 += wy[i] * r1; }
+        if (two_y && i > 0) { a10 += wy[i - 1] * r0; a11 += wy[i - 1] * r1; }
       }
-      v00 = t[0]; v01 = t[1]; v10 = t[2]; v11 = t[3];
+      if (!two_y) { a10 = a00; a11 = a01; }
+      v00 = a00; v01 = a01; v10 = a10; v11 = a11;
     } else {
-      v00 = load_px<U8>(sb, H, W, C, c, y0, x0, bgr); v01 = load_px<U8>(sb, H, W, C, c, y0, x1, bgr);
-      v10 = load_px<U8>(sb, H, W, C, c, y1, x0, bgr); v11 = load_px<U8>(sb, H, W, C, c, y1, x1, bgr);
+      v00 = load_px<U8>(sb, lut, H, W, C, c, y0, x0, bgr); v01 = load_px<U8>(sb, lut, H, W, C, c, y0, x1, bgr);
+      v10 = load_px<U8>(sb, lut, H, W, C, c, y1, x0, bgr); v11 = load_px<U8>(sb, lut, H, W, C, c, y1, x1, bgr);
     }
     db[((size_t)c * OH + oy) * OW + ox] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
   }

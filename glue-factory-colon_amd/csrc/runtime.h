@@ -14,7 +14,6 @@
 struct GfcKnobs {
   int gemm_tile;     // GFC_GEMM_TILE: 0 = automatic
   int attn_cfg;      // GFC_ATTN_CFG: 0 = automatic
-  int attn_split;    // GFC_ATTN_SPLIT: 0 = automatic key split
   int conv_kc;       // GFC_CONV_KC: 0 = automatic
   int conv_persist;  // GFC_CONV_PERSIST: -1 = automatic
   int ffn_fused;     // GFC_FFN_FUSED: -1 = automatic, 0 = GEMM + layernorm_gelu pass, 1 = row-owning fused GEMM
@@ -23,7 +22,6 @@ struct GfcKnobs {
   int gemm_epi;      // GFC_GEMM_EPI: 0 = automatic, 1 = float4 stores through the LDS transpose for every epilogue, 2 = direct
   int gemm_stagger;  // GFC_GEMM_STAGGER: start skew of the first-round GEMM workgroups in units of 8128 cycles per wave slot
   int nms_mode;      // GFC_NMS_MODE: 0 (default) = by problem size, 1 = LDS-image kernel, 2 = streaming kernel (waves walk column bands, rings in registers)
-  int nms_stream_min_tasks;  // GFC_NMS_STREAM_MIN_TASKS: wave tasks (bands x segments x images) from which mode 0 picks the streaming kernel; 0 = built-in
   int stem_f43;      // GFC_STEM_F43: 1 (default) = Winograd F(4x4,3x3) stem when its filters are supplied, 0 = F(2x2,3x3) stem
   int xcd_remap;     // GFC_XCD_REMAP: 1 (default) = XCD-aware work order (common.h: gfc_xcd_chunk), 0 = dispatch order
 };

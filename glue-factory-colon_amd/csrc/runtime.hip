@@ -17,7 +17,6 @@ const GfcKnobs& gfc_knobs() {
   std::call_once(g_knobs_once, [] {
     g_knobs.gemm_tile = env_int("GFC_GEMM_TILE", 0);
     g_knobs.attn_cfg = env_int("GFC_ATTN_CFG", 0);
-    g_knobs.attn_split = env_int("GFC_ATTN_SPLIT", 0);
     g_knobs.conv_kc = env_int("GFC_CONV_KC", 0);
     g_knobs.conv_persist = env_int("GFC_CONV_PERSIST", -1);
     g_knobs.ffn_fused = env_int("GFC_FFN_FUSED", -1);
@@ -26,7 +25,6 @@ const GfcKnobs& gfc_knobs() {
     g_knobs.gemm_epi = env_int("GFC_GEMM_EPI", 0);
     g_knobs.gemm_stagger = env_int("GFC_GEMM_STAGGER", 0);
     g_knobs.nms_mode = env_int("GFC_NMS_MODE", 0);
-    g_knobs.nms_stream_min_tasks = env_int("GFC_NMS_STREAM_MIN_TASKS", 0);
     g_knobs.stem_f43 = env_int("GFC_STEM_F43", 1);
     g_knobs.xcd_remap = env_int("GFC_XCD_REMAP", 1);
   });

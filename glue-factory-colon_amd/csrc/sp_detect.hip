@@ -465,7 +465,7 @@ static int launch_nms(const float* heat, int B, int H, int W, int border, const 
   if ((long long)bands * ((H + 127) / 128) * B >= 4096) segh = 128;
   const int segs = (H + segh - 1) / segh, ntasks = bands * segs;
   const int mode = gfc_knobs().nms_mode;
-  const long long thr = gfc_knobs().nms_stream_min_tasks > 0 ? gfc_knobs().nms_stream_min_tasks : 1800;
+  const long long thr = 1800;
   if (mode == 2 || (mode == 0 && (long long)bands * ((H + NMS_SEGH - 1) / NMS_SEGH) * B >= thr)) {
     hipLaunchKernelGGL(nms_stream_kernel<RAD>, dim3((ntasks + 3) / 4, B), dim3(256), 0, st, heat, H, W, border, valid_wh, out,
                        cand_thr, cand, cand_count, bands, ntasks, segh);

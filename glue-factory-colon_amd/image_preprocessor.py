@@ -144,9 +144,9 @@ class HostImageFeeder:
     def __len__(self):
         return len(self.raw)
 
-    def _stage(self, raw, copy_stream):
+    def _stage(self, raw, copy_stream, slot):
         """Issue the copies of one item on the copy stream; returns what `_finish` needs."""
-        views, meta = {}, []
+        views, meta, srcs = {}, [], []
         for tag in ("view0", "view1"):
             u8 = raw[tag]["image"]
             if u8.dtype != torch.uint8 or u8.ndim not in (2, 3):
@@ -155,19 +155,25 @@ class HostImageFeeder:
             size = (h, w) if self.pre.conf["resize"] is None else tuple(self.pre.get_new_image_size(h, w))
             # torch.Tensor([new_w / w, new_h / h]) (image.py:49): python floats rounded to fp32
             meta += [size[1] / w, size[0] / h, float(size[1]), float(size[0]), float(w), float(h)]
-            with torch.cuda.stream(copy_stream):
-                dev = u8.to(self.device, non_blocking=True)
+            srcs.append((tag, u8, size, (h, w)))
             self.h2d_bytes += u8.numel()
-            views[tag] = (dev, size, (h, w))
-        host_meta = torch.tensor(meta, dtype=torch.float32).pin_memory()
+        # the item's 12 numbers go through a slot of a pinned ring (allocated once); a slot comes round again after
+        # `depth` + 1 items, when its copy has long completed (checked: the event is synchronised, which returns at once)
+        ring, events = self._meta_ring
+        if events[slot] is not None:
+            events[slot].synchronize()
+        ring[slot] = torch.tensor(meta, dtype=torch.float32)
         with torch.cuda.stream(copy_stream):
-            dev_meta = host_meta.to(self.device, non_blocking=True)
+            for tag, u8, size, hw in srcs:
+                views[tag] = (u8.to(self.device, non_blocking=True), size, hw)
+            dev_meta = ring[slot].to(self.device, non_blocking=True)
             done = torch.cuda.Event()
             done.record(copy_stream)
-        return raw, views, dev_meta, host_meta, done
+        events[slot] = done
+        return raw, views, dev_meta, done
 
     def _finish(self, staged):
-        raw, views, dev_meta, host_meta, done = staged
+        raw, views, dev_meta, done = staged
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
         dev_meta.record_stream(main)
@@ -192,13 +198,16 @@ class HostImageFeeder:
 
     def __iter__(self):
         copy_stream = torch.cuda.Stream(self.device)
+        self._meta_ring = (torch.empty((self.depth + 1, 12), dtype=torch.float32).pin_memory(), [None] * (self.depth + 1))
         pending = deque()
         it = iter(self.raw)
         exhausted = False
+        n_staged = 0
         while True:
             while not exhausted and len(pending) < self.depth:
                 try:
-                    pending.append(self._stage(next(it), copy_stream))
+                    pending.append(self._stage(next(it), copy_stream, n_staged % (self.depth + 1)))
+                    n_staged += 1
                 except StopIteration:
                     exhausted = True
             if not pending:

@@ -11,7 +11,6 @@ sub-modules are parameter containers only; the forward pass is one call into lib
     model.matcher.name = glue_factory_colon_amd.lightglue
 """
 import ctypes
-import os
 import sys
 import threading
 from pathlib import Path
@@ -357,8 +356,7 @@ class LightGlue(nn.Module):
             kp = _pack_sides(kpts0.contiguous().float(), kpts1.contiguous().float())
             de = _pack_sides(desc0, desc1)
             so = _pack_sides(so0, so1) if so0 is not None else None
-            use_graph = (0 < b * (m + n) <= int(conf.graph_max_rows or 0) and self.trace is None
-                         and os.environ.get("GFC_LG_GRAPH", "1") != "0")
+            use_graph = 0 < b * (m + n) <= int(conf.graph_max_rows or 0) and self.trace is None
             if use_graph:
                 key = (b, m, n, device.index, so is not None, torch.cuda.current_stream(device).cuda_stream)
                 e = self._graphs.get(key) or self._graph_entry(key, kp, de, s0, s1, so, b, m, n)

@@ -1,5 +1,5 @@
 """Batch-1 regime (HPatches-style evaluation loop): one VGA pair at a time through TwoViewPipeline.
-    python tools/micro/batch1_probe.py [n_pairs]      (GFC_LG_GRAPH=0: matcher launches eagerly)
+    python tools/micro/batch1_probe.py [n_pairs]
 Prints ms per pair; run under `rocprofv3 --kernel-trace --stats` for the per-kernel split."""
 import os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
