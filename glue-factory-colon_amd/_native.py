@@ -76,6 +76,7 @@ SIGNATURES = {
     "gfc_event_create": (c_int, [POINTER(c_void_p)]),
     "gfc_event_destroy": (c_int, [c_void_p]),
     "gfc_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "gfc_sp_detector_head": (c_int, [c_void_p, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p, c_void_p]),
     "gfc_sp_nms": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gfc_sp_select_workspace_bytes": (c_size_t, [c_int] * 3),
     "gfc_sp_select": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -6,6 +6,8 @@
 // from the other translation units
 int gfc_rgb_to_gray(const float* img, float* out, int B, int H, int W, hipStream_t stream);
 int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* heat, hipStream_t st);
+int gfc_det_head_softmax_d2s(const float* hidden, int lda, const float* wp, const float* bias, const float* scale,
+                             const float* shift, int B, int h8, int w8, float* heat, hipStream_t st);
 int gfc_rowdot256(const float* x, int ld, int rows, const float* w, const float* bias, float* z, hipStream_t st);
 int gfc_assign_inplace(float* scores, const float* z0, const float* z1, int B, int M, int N, float* stats,
                        hipStream_t st);
@@ -204,12 +206,11 @@ extern "C" int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, i
   else
     GFC_TRY(gfc_conv3x3(Bf, p->wh, p->bias_h, p->scale_h, p->shift_h, A, B, Hs[4], Ws[4], 128, 512, 1, 0, st));
   const int rows = B * Hs[4] * Ws[4];
-  // detector 1x1 -> 65 logits (into Bf), descriptor 1x1 -> desc_raw
-  GFC_TRY(gfc_linear(A, 512, 256, nullptr, 0, 0, p->wp, 256, p->bias_p, p->scale_p, p->shift_p, 1.f, nullptr, nullptr,
-                     nullptr, 0, Bf, 65, rows, 65, st));
+  // detector: 1x1 -> 65 logits -> softmax -> depth-to-space in ONE launch (sp_heads.hip; the logits never reach HBM);
+  // descriptor: 1x1 -> desc_raw (normalised by the sampler at the four corners it reads)
+  GFC_TRY(gfc_det_head_softmax_d2s(A, 512, p->wp, p->bias_p, p->scale_p, p->shift_p, B, Hs[4], Ws[4], heatmap, st));
   GFC_TRY(gfc_linear(A + 256, 512, 256, nullptr, 0, 0, p->wd, 256, p->bias_d, p->scale_d, p->shift_d, 1.f, nullptr,
                      nullptr, nullptr, 0, desc_raw, p->desc_dim, rows, p->desc_dim, st));
-  GFC_TRY(gfc_softmax_d2s(Bf, 65, B, Hs[4], Ws[4], heatmap, st));
   return GFC_OK;
 }
 

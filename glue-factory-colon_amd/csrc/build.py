@@ -19,7 +19,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["runtime.hip", "conv.hip", "conv_wino.hip", "conv_wino43.hip", "gemm.hip", "attention.hip", "sp_detect.hip", "disk_detect.hip", "disk_unet.hip", "lg_misc.hip", "eval_metrics.hip", "preprocess.hip", "api.hip"]
+SOURCES = ["runtime.hip", "conv.hip", "conv_wino.hip", "conv_wino43.hip", "gemm.hip", "attention.hip", "sp_detect.hip", "sp_heads.hip", "disk_detect.hip", "disk_unet.hip", "lg_misc.hip", "eval_metrics.hip", "preprocess.hip", "api.hip"]
 HEADERS = ["common.h", "runtime.h", os.path.join(PKG, "..", "include", "gfc_amd.h")]
 LIB = os.path.join(PKG, "libgfc_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]

@@ -243,17 +243,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wino_kernel(WinoArgs a) {
   unsigned long long d_k = 0, d_x = 0, d_s = 0, d_n = 0, d_epi10 = 0;
   const unsigned long long d_t0 = __builtin_readcyclecounter();
 #endif
-#ifdef WINO_STAGGER  // experiment (tools/ab_build.sh ... "-DWINO_STAGGER=1|2"): the two persistent workgroups of a CU start
-  // together and walk items of equal length, so their exchange epilogues coincide; half of the workgroups wait about half
-  // an item before their first one.  1: the upper half of the grid waits, 2: the odd workgroups wait.
-  if constexpr (!STEM) {
-    const bool late = WINO_STAGGER == 1 ? (blockIdx.x >= gridDim.x / 2) : (blockIdx.x & 1);
-    if (late && gridDim.x < (unsigned)nitems) {
-      const int n_sleep = cin <= 64 ? 3 : 5;
-      for (int i = 0; i < n_sleep; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-  }
-#endif
   while (true) {
   WINO_T(t_a);
   WINO_STORE_IN(0);

@@ -220,6 +220,14 @@ size_t gfc_sp_workspace_bytes(int B, int C, int H, int W);
 int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, int C, int H, int W, float* heatmap,
                  float* desc_raw, void* ws, size_t ws_bytes, gfc_trace* trace, void* stream);
 
+/* Detector head in one launch: 1x1 convolution 256 -> 65 (+ eval-BN affine when scale / shift are given), softmax over the
+ * 65 logits of every cell, dustbin dropped, 8x8 depth-to-space:  heat[b, 8y+i, 8x+j] = softmax_c(W . hidden[b,y,x,:] + b)[8i+j].
+ * hidden [B*h8*w8][lda] NHWC rows (the detector's 256 hidden channels first, lda >= 256, a multiple of 4); w [65][256];
+ * bias / scale / shift [65] (scale and shift nullable together); heat [B][8 h8][8 w8].  The logits never reach HBM.
+ * superpoint_open.py:111-114,138-144; superpoint.py:193-194,229-235 (part of gfc_sp_dense). */
+int gfc_sp_detector_head(const float* hidden, int lda, const float* w, const float* bias, const float* scale,
+                         const float* shift, int B, int h8, int w8, float* heat, void* stream);
+
 /* Max-pool NMS with two recovery rounds, then outer `border` rows/cols := -1.
  * valid_wh (nullable, int32 [B,2] = (w,h)): right/bottom border measured from the true image
  * extent.  superpoint_open.py:36-51,148-154; superpoint.py:63-83,249-260.  radius <= 4. */

@@ -253,7 +253,7 @@ def test_export_from_host_uint8_images_with_gpu_preprocessing(tmp_path):
     # as arrays while the matched coordinate pairs are the same set.  Demanded: identical key-point sets, identical
     # sets of matched coordinate pairs, scores within 1e-4; the number of pairs whose arrays are element-wise equal is
     # recorded.
-    ferr = kerr = 0.0
+    ferr = 0.0
     total = identical_arrays = 0
     for name in seq:
         a, b = seq[name], bat[name]
@@ -270,23 +270,20 @@ def test_export_from_host_uint8_images_with_gpu_preprocessing(tmp_path):
         pb = pairs_of(np.round(b["keypoints0"], 2), np.round(b["keypoints1"], 2), b["matches0"], b["matching_scores0"])
         assert set(pa) == set(pb), (name, len(pa), len(pb), len(set(pa) ^ set(pb)))
         ferr = max(ferr, max(abs(pa[q] - pb[q]) for q in pa))
-        if same:
-            identical_arrays += 1
-            kerr = max(kerr, float(np.abs(a["keypoints0"] - b["keypoints0"]).max()),
-                       float(np.abs(a["keypoints1"] - b["keypoints1"]).max()))
+        identical_arrays += int(same)
         total += len(pa)
-    print(f"from-host vs CPU-preprocessed: score err {ferr:.3g}, key-point err {kerr:.3g} px, "
-          f"{identical_arrays}/40 pairs with element-wise identical arrays, {total} matches")
-    # scores: the inputs of the two loops differ by <= 2e-6 (two resize implementations), which the matcher amplifies;
-    # the 1e-4 bar of the path holds on IDENTICAL inputs (the comparison with `one` below: bit-identical integers)
-    assert ferr < 1e-3 and kerr < 1e-3, (ferr, kerr)
-    assert total > 40 * 100 and identical_arrays >= 20, (total, identical_arrays)
+    print(f"from-host vs CPU-preprocessed: score err {ferr:.3g}, {identical_arrays}/40 pairs with element-wise identical "
+          f"arrays (the others: near-tie order swaps inside the top-k lists), {total} matches")
+    # scores: the inputs of the two loops differ by <= 2e-6 (two resize implementations), which the matcher amplifies
+    # (measured 2.5e-5); the 1e-4 bar of the path holds on IDENTICAL inputs (`one` below: bit-identical integers)
+    assert ferr < 1e-4, ferr
+    assert total > 40 * 100, total
     # the same feeder items consumed pair by pair (resident tensors, no batching): identical integers again
     one = load_predictions(export_predictions(list(HostImageFeeder(raw, conf)), official_pipeline(), tmp_path / "one.npz",
                                               keys=keys))
     _assert_records_equal(one, bat, 40)
     record("c3_from_host_uint8_pb32_vs_cpu_preprocessed_sequential", pairs=40, matches_total=total, float_err=ferr,
-           keypoint_err_px=kerr, pairs_with_elementwise_identical_arrays=identical_arrays,
+           pairs_with_elementwise_identical_arrays=identical_arrays,
            h2d_mb_per_pair=feeder.h2d_bytes / 40 / 1e6)
 
 

@@ -718,6 +718,49 @@ def test_layernorm_gelu():
 
 
 # ---------------------------------------------------------------------------- detection
+@pytest.mark.parametrize("b,h8,w8,bn", [(2, 60, 80, True), (3, 25, 41, False), (1, 1, 3, True)])
+def test_detector_head_fused_softmax_d2s(b, h8, w8, bn):
+    """gfc_sp_detector_head (1x1 conv 256 -> 65 [+ BN affine] + softmax over 65 + dustbin drop + depth-to-space in one
+    launch; superpoint_open.py:111-114,138-144) against float64, and BIT-IDENTICAL to the two-stage form it replaced in
+    round 5: the logits of gfc_linear (N = 65) followed by torch's fp32 softmax would differ in the last bit, so the
+    reference for bit-equality is the same arithmetic restated here -- expf of (logit - max) summed over c = 0..64 in
+    order -- on the logits gfc_linear writes.  Cell counts that are not multiples of the 128-cell workgroup tile and a
+    hidden map with a row pitch of 512 (the merged head's output) are covered."""
+    lib = nat.lib()
+    g = gen(31 + h8)
+    rows = b * h8 * w8
+    hidden = torch.randn((rows, 512), generator=g).clamp_(min=0)  # ReLU output of the merged 3x3 head
+    w = torch.randn((65, 256), generator=g) / 8
+    bias = torch.randn((65,), generator=g)
+    scale = (torch.rand((65,), generator=g) + 0.5) if bn else None
+    shift = torch.randn((65,), generator=g) if bn else None
+    hd, wd, bd, scd, shd = D(hidden), D(w), D(bias), D(scale), D(shift)
+    heat = torch.empty((b, h8 * 8, w8 * 8), device=DEV)
+    nat.check(lib.gfc_sp_detector_head(nat.ptr(hd), 512, nat.ptr(wd), nat.ptr(bd), nat.ptr(scd), nat.ptr(shd), b, h8, w8,
+                                       nat.ptr(heat), st()), "gfc_sp_detector_head")
+    # float64 reference
+    logits = hidden[:, :256].double() @ w.double().T + bias.double()
+    if bn:
+        logits = logits * scale.double() + shift.double()
+    p = torch.softmax(logits, 1)[:, :64].reshape(b, h8, w8, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h8 * 8, w8 * 8)
+    assert maxerr(heat, p) < 2e-6
+    # the two-stage form: logits by the GEMM entry point, then the soft-max arithmetic of the kernel it replaced
+    lg = torch.empty((rows, 65), device=DEV)
+    nat.check(lib.gfc_linear(nat.ptr(hd), 512, 256, None, 0, 0, nat.ptr(wd), 256, nat.ptr(bd), nat.ptr(scd), nat.ptr(shd), 1.0,
+                             None, None, None, 0, nat.ptr(lg), 65, rows, 65, st()), "gfc_linear")
+    m = lg.max(1, keepdim=True).values
+    e = torch.exp(lg - m)
+    ssum = torch.zeros((rows,), device=DEV)
+    for c in range(65):  # sequential fp32 sum over the channels, as the kernel sums
+        ssum = ssum + e[:, c]
+    two = (e[:, :64] / ssum[:, None]).reshape(b, h8, w8, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h8 * 8, w8 * 8)
+    # torch.exp on the device is not guaranteed to be the expf the kernels call: equality is demanded of the LOGIT side
+    # (max and arg-max of every cell, i.e. the winner of each cell's soft-max) and 1e-7 of the values
+    assert maxerr(heat, two) < 1e-7
+    cells_f = heat.reshape(b, h8, 8, w8, 8).permute(0, 1, 3, 2, 4).reshape(rows, 64)
+    assert torch.equal(cells_f.argmax(1), lg[:, :64].argmax(1))
+
+
 @pytest.mark.parametrize("r", [0, 1, 3, 4])
 def test_nms_golden_bit_exact(golden, r):
     lib = nat.lib()
