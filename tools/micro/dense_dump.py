@@ -19,7 +19,12 @@ if sys.argv[1] == "--compare":
         print(f"{k}: {'bit-identical' if same else 'DIFFERENT max |d| = %.3g' % float((a[k] - b[k]).abs().max())}  shape {tuple(a[k].shape)}")
     sys.exit(0)
 
+from glue_factory_colon_amd import _native as nat  # noqa: E402
 from glue_factory_colon_amd import superpoint, superpoint_open, synthetic  # noqa: E402
+
+import ctypes  # noqa: E402
+if not hasattr(ctypes.CDLL(nat.LIB_PATH), "gfc_sp_detector_head"):  # an older build of the library (A/B): symbol of round 5
+    nat.SIGNATURES.pop("gfc_sp_detector_head")
 
 dev = torch.device("cuda", 0)
 out = {}

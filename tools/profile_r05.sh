@@ -1,9 +1,9 @@
-# Round-3 measurement set, one gpurun call:  bash tools/profile_r03.sh [tag]
+# Round-5 measurement set, one gpurun call:  bash tools/profile_r05.sh [tag]
 #   bench line (default command) -> rocprofv3 kernel stats -> three separate PMC passes (FETCH_SIZE, WRITE_SIZE,
 #   SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE; never combined with tracing domains) -> per-kernel summary JSON.
 # Copy gpurun_out/<tag>_{bench.json,kernel_stats.csv,pmc_summary.json} into profiles/ afterwards.
 set -e
-T=${1:-r03}
+T=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd $R
