@@ -132,12 +132,26 @@ __global__ __launch_bounds__(256, 2) void det_head_kernel(const float* __restric
   }
   if (tid < DH_ROWS) L[tid * DH_LP + 64] = (dust + bias[64]) * (scale ? scale[64] : 1.f) + (shift ? shift[64] : 0.f);
   __syncthreads();
-  if (tid < DH_ROWS) {
+  // statistics with the arithmetic of softmax_d2s_kernel -- max over the 65 logits, then the sum of expf(l - max) over
+  // c = 0..64 IN ORDER -- split so that every thread works: the maximum is order-independent (two threads per cell), the 65
+  // exponentials of a cell are evaluated once by all threads and kept in the tile (the outputs below are these same values
+  // divided by the sum: expf is not evaluated a second time), only the ordered sum is one thread per cell
+  {
+    const int q = tid >> 1, part = tid & 1;
     float m = -INFINITY;
-    for (int c = 0; c < 65; ++c) m = fmaxf(m, L[tid * DH_LP + c]);
+    for (int c = part * 33; c < (part ? 65 : 33); ++c) m = fmaxf(m, L[q * DH_LP + c]);
+    m = fmaxf(m, __shfl_xor(m, 1));
+    if (part == 0) mx[q] = m;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < DH_ROWS * 65; idx += 256) {
+    const int q = idx / 65;
+    L[idx] = expf(L[idx] - mx[q]);
+  }
+  __syncthreads();
+  if (tid < DH_ROWS) {
     float s = 0.f;
-    for (int c = 0; c < 65; ++c) s += expf(L[tid * DH_LP + c] - m);
-    mx[tid] = m;
+    for (int c = 0; c < 65; ++c) s += L[tid * DH_LP + c];
     sinv[tid] = s;
     const long long cell = row0 + tid, per_img = (long long)h8 * w8;
     const long long b = cell / per_img;
@@ -145,13 +159,13 @@ __global__ __launch_bounds__(256, 2) void det_head_kernel(const float* __restric
     cbase[tid] = cell < rows ? ((b * h8 * 8 + (long long)y * 8) * (w8 * 8) + x * 8) : -1;
   }
   __syncthreads();
-  // ---- depth-to-space: heat[b, 8y + i, 8x + j] = exp(L[cell][8i + j] - max) / sum; consecutive threads walk (cell, j) ----
+  // ---- depth-to-space: heat[b, 8y + i, 8x + j] = exp(l[cell][8i + j] - max) / sum; consecutive threads walk (cell, j) ----
   const int W8 = w8 * 8;
 #pragma unroll 4
   for (int idx = tid; idx < 8 * DH_ROWS * 8; idx += 256) {
     const int i = idx >> 10, q = (idx >> 3) & (DH_ROWS - 1), j = idx & 7;
     const long long base = cbase[q];
-    if (base >= 0) heat[base + (long long)i * W8 + j] = expf(L[q * DH_LP + 8 * i + j] - mx[q]) / sinv[q];
+    if (base >= 0) heat[base + (long long)i * W8 + j] = L[q * DH_LP + 8 * i + j] / sinv[q];
   }
 }
 

@@ -132,9 +132,8 @@ class HostImageFeeder:
     Yields batch-1 items (`image` [1,C,h,w] float32, `scales` [1,2], `image_size` [1,2], `original_image_size` [1,2],
     `transform` [1,3,3] float64 on the host), i.e. what the reference's DataLoader collates."""
 
-    def __init__(self, raw_items, conf, device="cuda", depth=64, bgr=False, background=True):
+    def __init__(self, raw_items, conf, device="cuda", depth=64, bgr=False):
         self.raw, self.pre, self.depth, self.bgr = raw_items, ImagePreprocessor(conf), max(1, int(depth)), bool(bgr)
-        self.background = bool(background)
         if self.pre.conf["square_pad"]:
             raise NotImplementedError("square_pad on the host-image path")
         if self.pre.conf["interpolation"] != "bilinear":
@@ -198,9 +197,6 @@ class HostImageFeeder:
         return item
 
     def __iter__(self):
-        if self.background:
-            yield from self._iter_background()
-            return
         copy_stream = torch.cuda.Stream(self.device)
         ring = self.depth + 1
         self._meta_ring = (torch.empty((ring, 12), dtype=torch.float32).pin_memory(), [None] * ring)
@@ -218,62 +214,3 @@ class HostImageFeeder:
             if not pending:
                 return
             yield self._finish(pending.popleft())
-
-    def _iter_background(self):
-        """The same items, produced by a host thread of their own (`background=True`, the default): the thread issues the
-        copies on a copy stream and the resize launches on a preprocessing stream, up to `depth` items ahead; the
-        consumer only makes its stream wait for an item's event.  The per-item host work (two copies, two launches,
-        the dictionaries) then runs while the consumer's thread sits in the export loop's own host synchronisations
-        instead of in front of every batch (measured: the loop fed from host images was host-bound)."""
-        import queue
-        import threading
-
-        q = queue.Queue(maxsize=self.depth)
-        stop = threading.Event()
-        ring = self.depth + 3  # queued items + the one being staged + the one the consumer holds
-        self._meta_ring = (torch.empty((ring, 12), dtype=torch.float32).pin_memory(), [None] * ring)
-
-        def put(x):
-            while not stop.is_set():
-                try:
-                    q.put(x, timeout=0.1)
-                    return True
-                except queue.Full:
-                    continue
-            return False
-
-        def produce():
-            try:
-                torch.cuda.set_device(self.device)
-                copy_stream, pre_stream = torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)
-                for n, raw in enumerate(self.raw):
-                    staged = self._stage(raw, copy_stream, n % ring)
-                    with torch.cuda.stream(pre_stream):
-                        item = self._finish(staged)
-                        ready = torch.cuda.Event()
-                        ready.record(pre_stream)
-                    if not put((item, ready)):
-                        return
-                put(None)
-            except BaseException as e:  # noqa: BLE001 -- handed to the consumer, raised in its thread
-                put(e)
-
-        worker = threading.Thread(target=produce, daemon=True)
-        worker.start()
-        try:
-            while True:
-                got = q.get()
-                if got is None:
-                    return
-                if isinstance(got, BaseException):
-                    raise got
-                item, ready = got
-                main = torch.cuda.current_stream(self.device)
-                main.wait_event(ready)
-                for tag in ("view0", "view1"):
-                    for t in item[tag].values():
-                        if isinstance(t, torch.Tensor) and t.is_cuda:
-                            t.record_stream(main)
-                yield item
-        finally:
-            stop.set()

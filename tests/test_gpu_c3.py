@@ -279,10 +279,10 @@ def test_export_from_host_uint8_images_with_gpu_preprocessing(tmp_path):
     assert ferr < 1e-4, ferr
     assert total > 40 * 100, total
     # the same feeder items consumed pair by pair (resident tensors, no batching): identical integers again
-    one = load_predictions(export_predictions(list(HostImageFeeder(raw, conf, background=False)), official_pipeline(),
+    one = load_predictions(export_predictions(list(HostImageFeeder(raw, conf)), official_pipeline(),
                                               tmp_path / "one.npz", keys=keys))
     _assert_records_equal(one, bat, 40)
-    # an error inside the feeder's producer thread surfaces in the consumer
+    # a float image is not a decoded image
     bad = [dict(raw[0]), {**raw[1], "view1": {"image": raw[1]["view1"]["image"].float()}}]
     with pytest.raises(ValueError, match="expected a decoded uint8 image"):
         list(HostImageFeeder(bad, conf))

@@ -178,10 +178,14 @@ def test_config5_disk_plus_lightglue_pipeline_vs_oracle():
     from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
     from oracle import lightglue as olg
 
+    # view 1 = view 0 displaced by (16, 16) pixels: the U-Net pools four times (stride 16), so only displacements that are
+    # multiples of 16 leave heat-map and descriptors equivariant away from the borders -- the (16, 8) shift of the SuperPoint
+    # workloads (stride 8) gave this configuration a weak signal (round 4: 35 matches of 512 key points)
+    from glue_factory_colon_amd import synthetic
     h, w, k = 240, 320, 512
-    g = torch.Generator().manual_seed(55)
-    img0 = torch.rand((1, 3, h, w), generator=g)
-    img1 = (img0.roll(7, -1) * 0.9 + 0.05 * torch.rand((1, 3, h, w), generator=g)).contiguous()
+    g0, g1 = synthetic.synthetic_pairs(1, h, w, seed=55, dx=16, dy=16)
+    img0 = torch.cat([g0 * 0.8, g0, g0 * 0.9], 1).contiguous()
+    img1 = torch.cat([g1 * 0.8, g1, g1 * 0.9], 1).contiguous()
     pipe = TwoViewPipeline({
         "extractor": {"name": "extractors.disk_kornia", "weights": "synthetic", "max_num_keypoints": k},
         "matcher": {"name": "matchers.lightglue_pretrained", "features": "disk", "weights": "synthetic",
@@ -195,8 +199,15 @@ def test_config5_disk_plus_lightglue_pipeline_vs_oracle():
                     pred["descriptors1"].cpu(), size.cpu(), size.cpu(), filter_threshold=0.1)
     assert torch.equal(pred["matches0"].cpu(), ref["matches0"]) and torch.equal(pred["matches1"].cpu(), ref["matches1"])
     assert (pred["matching_scores0"].cpu() - ref["matching_scores0"]).abs().max() < 1e-4
+    n_matches = int((ref["matches0"] >= 0).sum())
+    # the matches follow the known displacement
+    ok = pred["matches0"][0] >= 0
+    d = pred["keypoints1"][0][pred["matches0"][0][ok]] - pred["keypoints0"][0][ok]
+    on_shift = int(((d - torch.tensor([16.0, 16.0], device=DEV)).abs().max(1).values < 0.5).sum())
     from parity_utils import record
-    record("config5_pipeline", matches=int((ref["matches0"] >= 0).sum()), keypoints=int(pred["keypoints0"].shape[1]))
+    record("config5_pipeline", matches=n_matches, keypoints=int(pred["keypoints0"].shape[1]), matches_on_the_known_shift=on_shift)
+    print(f"config 5 pipeline: {n_matches} matches of {int(pred['keypoints0'].shape[1])} key points, {on_shift} on the known shift")
+    assert n_matches >= 35, (n_matches, on_shift)  # tightened once measured
 
 
 def test_config5_pair_batched_equals_pair_by_pair():
