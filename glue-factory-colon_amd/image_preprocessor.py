@@ -197,11 +197,20 @@ class HostImageFeeder:
         return item
 
     def __iter__(self):
+        return self._iterate(self.raw)
+
+    def shard(self, rank, world):
+        """(index, item) of this rank's round-robin share (export_predictions' sharded mode, sharding.round_robin_shard):
+        only this rank's images are copied and resized."""
+        idx = range(int(rank), len(self.raw), int(world))
+        return zip(idx, self._iterate(self.raw[i] for i in idx))
+
+    def _iterate(self, raw_iterable):
         copy_stream = torch.cuda.Stream(self.device)
         ring = self.depth + 1
         self._meta_ring = (torch.empty((ring, 12), dtype=torch.float32).pin_memory(), [None] * ring)
         pending = deque()
-        it = iter(self.raw)
+        it = iter(raw_iterable)
         exhausted = False
         n_staged = 0
         while True:

@@ -207,7 +207,7 @@ def test_config5_disk_plus_lightglue_pipeline_vs_oracle():
     from parity_utils import record
     record("config5_pipeline", matches=n_matches, keypoints=int(pred["keypoints0"].shape[1]), matches_on_the_known_shift=on_shift)
     print(f"config 5 pipeline: {n_matches} matches of {int(pred['keypoints0'].shape[1])} key points, {on_shift} on the known shift")
-    assert n_matches >= 35, (n_matches, on_shift)  # tightened once measured
+    assert n_matches >= 60 and on_shift >= 0.6 * n_matches, (n_matches, on_shift)  # measured: 94 matches, 75 on the shift (round 4, (7, 0) shift of white noise: 35)
 
 
 def test_config5_pair_batched_equals_pair_by_pair():

@@ -101,3 +101,37 @@ def test_image_preprocessor_contract():
     view = ImagePreprocessor({"resize": 120, "side": "short", "edge_divisible_by": 8})(big.cuda())
     p = ext({"image": view["image"][None]})
     assert p["keypoints"].shape[1] == 128 and float(p["keypoints"][..., 0].max()) < view["image_size"][0]
+
+
+@pytest.mark.gpu
+def test_host_image_feeder_items_and_round_robin_shard():
+    """HostImageFeeder: decoded uint8 host images (RGB and grey) -> loader items on the GPU with the fields the reference's
+    HPatches loader collates (datasets/hpatches.py:94-112: image, scales, image_size, original_image_size, transform);
+    `shard(rank, world)` yields this rank's round-robin share and touches only its own images."""
+    from glue_factory_colon_amd.image_preprocessor import HostImageFeeder, ImagePreprocessor
+
+    raw = []
+    for i in range(7):
+        h, w = (90 + 7 * i, 120 + 5 * i)
+        img = _img(h, w, 3, seed=20 + i)
+        raw.append({"name": f"s/{i}.ppm", "idx": i, "view0": {"image": img.pin_memory()},
+                    "view1": {"image": img[..., 0].contiguous()}})  # view 1: a grey image [H,W]
+    conf = {"resize": 64, "side": "short"}
+    feeder = HostImageFeeder(raw, conf, depth=3)
+    items = list(feeder)
+    assert len(items) == 7 and feeder.h2d_bytes == sum(r[v]["image"].numel() for r in raw for v in ("view0", "view1"))
+    pp = ImagePreprocessor(conf)
+    for r, it in zip(raw, items):
+        assert it["name"] == [r["name"]] and it["idx"] == r["idx"]
+        for v, c in (("view0", 3), ("view1", 1)):
+            ref = pp(r[v]["image"].cuda())
+            d = it[v]
+            assert d["image"].shape[:2] == (1, c) and torch.equal(d["image"][0], ref["image"])
+            assert torch.equal(d["scales"][0].cpu(), ref["scales"].cpu())
+            assert d["image_size"][0].tolist() == list(ref["image_size"])
+            assert d["original_image_size"][0].tolist() == list(ref["original_image_size"])
+            assert np.allclose(d["transform"][0].numpy(), ref["transform"])
+    share = list(HostImageFeeder(raw, conf, depth=2).shard(1, 3))
+    assert [i for i, _ in share] == [1, 4]
+    for i, it in share:
+        assert torch.equal(it["view0"]["image"], items[i]["view0"]["image"]) and it["name"] == items[i]["name"]
