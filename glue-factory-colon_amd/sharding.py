@@ -44,8 +44,9 @@ def round_robin_shard(n_items: int, rank: int, world: int) -> range:
 
 def gather_records(records: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:
     """Gather one equally-shaped record tensor per rank to `dst` (single collective).
-    Returns the list on dst, None elsewhere; a no-op list without a process group."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    Returns the list on dst, None elsewhere; a no-op list without a process group (with a one-rank group the collective
+    still runs: tests/test_gpu_rccl.py exercises the RCCL calls of the path on a one-GPU box that way)."""
+    if not dist.is_initialized():
         return [records]
     world, rank = dist.get_world_size(), dist.get_rank()
     records = records.contiguous()
