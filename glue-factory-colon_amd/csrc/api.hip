@@ -5,7 +5,6 @@
 
 // from the other translation units
 int gfc_rgb_to_gray(const float* img, float* out, int B, int H, int W, hipStream_t stream);
-int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* heat, hipStream_t st);
 int gfc_det_head_softmax_d2s(const float* hidden, int lda, const float* wp, const float* bias, const float* scale,
                              const float* shift, int B, int h8, int w8, float* heat, hipStream_t st);
 int gfc_rowdot256(const float* x, int ld, int rows, const float* w, const float* bias, float* z, hipStream_t st);

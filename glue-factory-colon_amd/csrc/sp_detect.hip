@@ -5,52 +5,8 @@
 #include <type_traits>
 #include <utility>
 
-// ------------------------------------------------------------------------------------------
-// softmax over 65 logits per 8x8 cell, drop the dustbin, depth-to-space:
-//   S[b, 8y+i, 8x+j] = P[b, 8i+j, y, x]      (superpoint_open.py:139-144; superpoint.py:231-235)
-// logits: [B*h*w][ld] (NHWC GEMM output, 65 valid columns).  One workgroup per cell row.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restrict__ logits, int ld, int h, int w,
-                                                          float* __restrict__ heat) {
-  extern __shared__ float sm[];  // [w][65] logits, then [w] max, [w] sum
-  float* lg = sm;
-  float* mx = sm + w * 65;
-  float* sinv = mx + w;
-  const int y = blockIdx.x % h, b = blockIdx.x / h;
-  const float* src = logits + ((size_t)b * h + y) * w * ld;
-  for (int i = threadIdx.x; i < w * 65; i += 256) {
-    int x = i / 65, c = i - x * 65;
-    lg[i] = src[(size_t)x * ld + c];
-  }
-  __syncthreads();
-  for (int x = threadIdx.x; x < w; x += 256) {
-    float m = -INFINITY;
-    for (int c = 0; c < 65; ++c) m = fmaxf(m, lg[x * 65 + c]);
-    float s = 0.f;
-    for (int c = 0; c < 65; ++c) s += expf(lg[x * 65 + c] - m);
-    mx[x] = m;
-    sinv[x] = s;
-  }
-  __syncthreads();
-  const int W8 = w * 8;
-  float* dst = heat + ((size_t)b * h * 8 + y * 8) * W8;
-  for (int i = threadIdx.x; i < 8 * W8; i += 256) {
-    int row = i / W8, col = i - row * W8;
-    int x = col >> 3, j = col & 7;
-    dst[(size_t)row * W8 + col] = expf(lg[x * 65 + row * 8 + j] - mx[x]) / sinv[x];
-  }
-}
-
-int gfc_softmax_d2s(const float* logits, int ld, int B, int h, int w, float* heat, hipStream_t st) {
-  size_t lds = (size_t)(w * 65 + 2 * w) * sizeof(float);
-  if (lds > 160 * 1024) return GFC_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)softmax_d2s_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(softmax_d2s_kernel, dim3(B * h), dim3(256), lds, st, logits, ld, h, w, heat);
-  GFC_LAUNCH_CHECK();
-  return GFC_OK;
-}
-
+// (The softmax over the 65 logits of a cell + depth-to-space lives in sp_heads.hip since round 5, fused with the
+// detector's 1x1 convolution.)
 // ------------------------------------------------------------------------------------------
 // NMS (superpoint_open.py:36-51 == superpoint.py:63-83) fused with the border kill
 // (superpoint_open.py:148-154; superpoint.py:249-260).

@@ -6,7 +6,7 @@
 // writing [rows, 65] logits to HBM plus softmax_d2s_kernel reading them back (158 MB round trip
 // per 64 VGA images).  Here one workgroup owns 128 cells: the 64 heat-map channels on the matrix pipe (two 32-column
 // tiles), the dustbin channel as one fmaf chain per cell on the VALU, the logits tile in LDS, statistics and outputs
-// with the arithmetic of softmax_d2s_kernel.
+// with the arithmetic of the softmax_d2s_kernel of rounds 1-4 (max, then the sum of expf(l - max) over c = 0..64 in order).
 //
 // Bit-identical to the two-launch form: the K loop feeds the MFMAs exactly like gemm_nt_kernel (lane half h supplies
 // k = 8g + 4h + s in step s of k group g), v_mfma_f32_32x32x2_f32 accumulates its two products in k order with one
