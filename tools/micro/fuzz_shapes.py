@@ -1,5 +1,5 @@
 """Randomised shape sweep of gfc_conv3x3_wino / gfc_lg_assign / gfc_disk_nms_select / gfc_linear / gfc_attention /
-gfc_ffn_fused / gfc_lg_forward_ragged against torch float64 / the oracle / the single-pair calls
+gfc_ffn_fused / gfc_lg_forward_ragged / gfc_sp_detector_head / gfc_preprocess_resize against torch float64 / the oracle / the single-pair calls
 (run on the GPU box: python tools/micro/fuzz_shapes.py [n_cases]).  Prints the worst error and any failing shape."""
 import ctypes
 import os
@@ -344,6 +344,58 @@ def run(n_cases=60, seed=2024):
                 bad.append(("ragged", dim, [tuple(it["keypoints0"].shape[1:2]) + tuple(it["keypoints1"].shape[1:2]) for it in items],
                             i, same, err, la))
     print("ragged forward: worst", worst, "bad", bad)
+    failures += bad
+
+    # ---- round 5: fused detector head (any cell count, BN or not, row pitch 256 or 512) against float64 ----
+    bad, worst = [], 0.0
+    for case in range(n_cases):
+        b_, h8, w8, bn, lda = ri(1, 4), ri(1, 40), ri(1, 50), ri(0, 1), (256, 512)[ri(0, 1)]
+        rows = b_ * h8 * w8
+        hidden = torch.randn((rows, lda), generator=g).clamp_(min=0)
+        wt = torch.randn((65, 256), generator=g) / 8
+        bias = torch.randn((65,), generator=g)
+        scale = (torch.rand((65,), generator=g) + 0.5) if bn else None
+        shift = torch.randn((65,), generator=g) if bn else None
+        hd, wd, bd = hidden.to(DEV), wt.to(DEV), bias.to(DEV)
+        scd, shd = (scale.to(DEV), shift.to(DEV)) if bn else (None, None)
+        guard = 64
+        heat = torch.full((b_ * h8 * 8 * w8 * 8 + guard,), float("nan"), device=DEV)
+        nat.check(lib.gfc_sp_detector_head(nat.ptr(hd), lda, nat.ptr(wd), nat.ptr(bd), nat.ptr(scd), nat.ptr(shd), b_, h8, w8,
+                                           nat.ptr(heat), st), "gfc_sp_detector_head")
+        torch.cuda.synchronize()
+        logits = hidden[:, :256].double() @ wt.double().T + bias.double()
+        if bn:
+            logits = logits * scale.double() + shift.double()
+        ref = torch.softmax(logits, 1)[:, :64].reshape(b_, h8, w8, 8, 8).permute(0, 1, 3, 2, 4).reshape(-1)
+        err = (heat[:-guard].double().cpu() - ref).abs().max().item()
+        untouched = bool(torch.isnan(heat[-guard:]).all())
+        worst = max(worst, err)
+        if not err < 2e-6 or not untouched:
+            bad.append(("det_head", b_, h8, w8, bn, lda, err, untouched))
+    print("detector head: worst", worst, "bad", bad)
+    failures += bad
+
+    # ---- round 5: resize kernel (uint8 HWC / float CHW, any sizes up and down, antialias on / off) against the oracle ----
+    from glue_factory_colon_amd import image_preprocessor as ip
+    from oracle import preprocess as opp
+    bad, worst = [], 0.0
+    for case in range(n_cases):
+        h, w, c = ri(8, 260), ri(8, 260), (1, 3)[ri(0, 1)]
+        oh, ow = ri(4, 200), ri(4, 200)
+        if max(h / oh, w / ow) > 12:  # (kernel windows above 63 taps are refused: > ~30x down-scaling)
+            continue
+        ac, aa = (None, True)[ri(0, 1)] if ri(0, 3) == 0 else None, bool(ri(0, 1))
+        u8 = torch.randint(0, 256, (h, w, c), generator=g, dtype=torch.uint8)
+        x = opp.numpy_image_to_torch(u8.numpy() if c == 3 else u8[..., 0].numpy())
+        ref = opp.kornia_resize(x, (oh, ow), ac, aa)
+        out_u = ip.resize((u8 if c == 3 else u8[..., 0].contiguous()).to(DEV), (oh, ow), ac, aa).cpu()
+        out_f = ip.resize(x.to(DEV), (oh, ow), ac, aa).cpu()
+        err = (out_u - ref).abs().max().item()
+        same = torch.equal(out_u, out_f)
+        worst = max(worst, err)
+        if not err < 3e-6 or not same:
+            bad.append(("resize", h, w, c, oh, ow, ac, aa, err, same))
+    print("resize: worst", worst, "bad", bad)
     return failures + bad
 
 if __name__ == "__main__":
