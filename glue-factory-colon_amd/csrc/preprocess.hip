@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void resize_kernel(const void* __restrict__ sr
     fy = scy * oy; fx = scx * ox;
   } else {
     const float scy = (float)H / (float)OH, scx = (float)W / (float)OW;
-    fy = fmaxf(scy * (oy + 0.5f) - 0.5f, 0.f); fx = fmaxf(scx * (ox + 0.5f) - 0.5f, 0.f);
+    // one rounding, as torch's CPU kernel evaluates scale * (dst + 0.5) - 0.5 (its translation unit is built with FMA
+    // contraction: checked bit for bit against F.interpolate, tools/micro/fuzz_shapes.py; with two roundings the source
+    // coordinate is off by an ulp at coordinates > 64, i.e. the tap weight by ~1e-5)
+    fy = fmaxf(fmaf(scy, oy + 0.5f, -0.5f), 0.f); fx = fmaxf(fmaf(scx, ox + 0.5f, -0.5f), 0.f);
   }
   const int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1);
   const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);

@@ -61,11 +61,11 @@ def test_resize_gpu_vs_oracle(hw, size, ac, aa):
     out_u = ip.resize(u8.cuda(), size, ac, aa).cpu()
     assert torch.equal(out_f, out_u)  # the fused uint8 path converts exactly like numpy_image_to_torch
     assert out_f.shape == ref.shape
-    assert float((out_f - ref).abs().max()) <= 2e-6, float((out_f - ref).abs().max())
+    assert float((out_f - ref).abs().max()) <= 5e-7, float((out_f - ref).abs().max())
     # grey image, batched float input, BGR flip
     g8 = u8[..., 0].contiguous()
     og = ip.resize(g8.cuda(), size, ac, aa).cpu()
-    assert float((og - ref[:1]).abs().max()) <= 2e-6
+    assert float((og - ref[:1]).abs().max()) <= 5e-7
     ob = ip.resize(torch.stack([x, x.flip(0)]).cuda(), size, ac, aa).cpu()
     assert torch.equal(ob[0], out_f) and torch.equal(ob[1], out_f.flip(0))
     obgr = ip.resize(u8.flip(-1).contiguous().cuda(), size, ac, aa, bgr=True).cpu()
@@ -83,7 +83,7 @@ def test_image_preprocessor_contract():
         d = pp(inp)
         ref = opp.preprocess(x, resize=60, side="short")
         assert sorted(d) == sorted(ref)
-        assert float((d["image"].cpu() - ref["image"]).abs().max()) <= 2e-6
+        assert float((d["image"].cpu() - ref["image"]).abs().max()) <= 5e-7
         assert torch.allclose(d["scales"].cpu(), ref["scales"]) and list(d["image_size"]) == list(ref["image_size"])
         assert np.allclose(d["transform"], ref["transform"]) and list(d["original_image_size"]) == [160, 120]
     sq = ImagePreprocessor({"resize": 60, "side": "short", "square_pad": True, "add_padding_mask": True})(x.cuda())
