@@ -36,7 +36,9 @@ def record(name, **kw):
 
 
 def _key(kp):
-    return (kp[:, 1].round().long() * 100000 + kp[:, 0].round().long()).tolist()
+    # the pixel a key point sits in (coordinates are pixel centres x + 0.5: floor, not round -- round-half-to-even maps
+    # x = 1.5 and x = 2.5 to the same key, which collides as soon as neighbouring pixels are both key points: nms_radius 0)
+    return (kp[:, 1].floor().long() * 100000 + kp[:, 0].floor().long()).tolist()
 
 
 def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, tie_tol=2e-6, score_tol=1e-5,

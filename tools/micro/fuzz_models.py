@@ -68,7 +68,8 @@ def run(n_cases=24, seed=99):
                         compare_keypoints(f"fuzz_{case}_{i}", p["keypoints"][0], p["keypoint_scores"][0], p["descriptors"][0],
                                           o["keypoints"][i], o["keypoint_scores"][i], o["descriptors"][i], radius=max(r, 1))
             except AssertionError as e:
-                bad.append((tag, "assert", str(e)[:200]))
+                import traceback
+                bad.append((tag, "assert", str(e)[:200], traceback.format_exc().splitlines()[-3:]))
     print("superpoint modules: bad", bad)
     failures = list(bad)
 
