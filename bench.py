@@ -271,6 +271,32 @@ def c3_regime(dev, n_pairs: int = 128, n_host: int = 64):
             **compare(sorted(fresh, key=lambda e: e[0]), base)}
         legs["pair_batch32_first_call_of_fresh_pipeline"]["integers_equal_to_first_leg"] = \
             legs["pair_batch32_first_call_of_fresh_pipeline"]["pairs_differing"] == 0
+        # the list's real structure: the five pairs of an HPatches sequence share their view 0 (datasets/hpatches.py:98-99);
+        # with `view_key` the pair-batched loop extracts a shared image once per batch
+        seq_items = synthetic.hpatches_shaped_pairs(n_pairs, device=dev, shared_view0=True)
+        seqs = {}
+        for tag, vk in (("pair_batch32", None),
+                        ("pair_batch32_view_dedupe", lambda item, i: (item["scene"][0], 1) if i == 0 else None)):
+            def run_seq():
+                out = []
+                ep._export_loop(enumerate(seq_items), pipe, "cuda", keys, optional, None, False, 1, out, 32, vk)
+                return out
+            run_seq()
+            best = None
+            for _ in range(2):
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                out = run_seq()
+                torch.cuda.synchronize(dev)
+                dt = time.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            seqs[tag] = {"pairs_per_s": round(n_pairs / best, 1),
+                         "matches_total": sum(int((rec["matches0"] >= 0).sum()) for _, _, rec in out),
+                         "_out": sorted(out, key=lambda e: e[0])}
+        seqs["integers_equal"] = compare(seqs["pair_batch32_view_dedupe"].pop("_out"), seqs["pair_batch32"].pop("_out"))["pairs_differing"] == 0
+        seqs["sample"] = (f"{n_pairs} pairs in sequences of five that share their view-0 image (the structure of the HPatches list), "
+                          "same pipeline; `view_dedupe` = export_predictions(view_key=...) extracts a shared image once per pair batch")
+        res["hpatches_sequences"] = seqs
         # the loop that FEEDS the path (datasets/hpatches.py:94-112 + utils/image.py:33-72): decoded uint8 images in
         # pinned host memory -> async H2D on a copy stream -> gfc_preprocess_resize (short side 480, antialias) ->
         # forward_pairs(32) -> records; beside it the same images already preprocessed and resident in HBM

@@ -73,9 +73,9 @@ def _process(model, data, keys, optional_keys, callback_fn, as_half):
     return _record(model(data), data, keys, optional_keys, callback_fn, as_half)
 
 
-def _process_batch(model, datas, keys, optional_keys, callback_fn, as_half):
+def _process_batch(model, datas, keys, optional_keys, callback_fn, as_half, view_key=None):
     """`pair_batch` consecutive pairs through one `forward_pairs` call; one record per pair."""
-    return _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half)()
+    return _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half, view_key)()
 
 
 class _HostStage:
@@ -101,12 +101,18 @@ class _HostStage:
 _HOST_STAGE = _HostStage()
 
 
-def _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half):
+def _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half, view_key=None):
     """Forward + record building of one pair batch; returns a function that completes the host copy and yields the
     records.  ONE device-to-host copy per dtype for the whole batch (instead of one synchronising copy per pair and
     key), issued on a side stream into pinned memory: the caller may queue the next batch's forward before it calls the
     function, so that slicing this batch's records overlaps the next batch's kernels."""
-    preds = model.forward_pairs(datas) if hasattr(model, "forward_pairs") else [model(d) for d in datas]
+    if hasattr(model, "forward_pairs"):
+        if view_key is not None:
+            preds = model.forward_pairs(datas, view_keys=[(view_key(d, 0), view_key(d, 1)) for d in datas])
+        else:
+            preds = model.forward_pairs(datas)
+    else:
+        preds = [model(d) for d in datas]
     preds = [_record(p, d, keys, optional_keys, callback_fn, as_half, to_host=False) for p, d in zip(preds, datas)]
     by_dtype = {}
     for i, p in enumerate(preds):
@@ -253,8 +259,12 @@ def _decode_blocks(blocks):
 
 @torch.no_grad()
 def export_predictions(loader, model, output_file, as_half=False, keys="*", callback_fn=None, optional_keys=(),
-                       workers=1, rank=None, world=None, pair_batch=1):
+                       workers=1, rank=None, world=None, pair_batch=1, view_key=None):
     """pair_batch: number of consecutive pairs processed by one `model.forward_pairs` call (module docstring).
+    view_key (with pair_batch > 1): `view_key(item, i) -> hashable or None` names the image of view i of a loader item;
+    views of one pair batch with equal non-None names are extracted ONCE (TwoViewPipeline.forward_pairs).  For the
+    HPatches list (datasets/hpatches.py:98-112: view 0 of every pair of a sequence is the sequence's image 1):
+    `view_key=lambda item, i: (item["scene"][0], 1) if i == 0 else None`.  Records are unchanged.
     rank / world (default: the torch.distributed process group, if one is initialised): the pair list is shared
     out round-robin over the ranks (one process per GPU, no data-path collective); at the end ONE gather brings every
     rank's records to rank 0 (RCCL over xGMI: one direct peer write per rank), which writes the single
@@ -276,7 +286,7 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
         local = []
         try:
             _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half,
-                         workers, local, pair_batch)
+                         workers, local, pair_batch, view_key)
         except Exception as e:  # noqa: BLE001 -- re-raised below, after the other ranks have been told
             failure = e
         blocks, failed = _gather_to_rank0(local, failure is not None, rank, world, device)
@@ -301,7 +311,7 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
         return output_file
     local = []
     _export_loop(enumerate(loader), model, device, keys, optional_keys, callback_fn, as_half, workers, local,
-                 pair_batch)
+                 pair_batch, view_key)
     records = {}
     for _, name, rec in sorted(local, key=lambda e: e[0]):
         if name not in records:  # like the reference: a duplicate group name is skipped
@@ -332,7 +342,8 @@ def _batches(indexed, n):
         yield chunk
 
 
-def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out, pair_batch=1):
+def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_half, workers, out, pair_batch=1,
+                 view_key=None):
     """Process (index, item) pairs; appends (index, name, record) to `out`."""
     pair_batch = max(1, int(pair_batch or 1))
     if workers > 1 and pair_batch > 1 and device != "cpu":
@@ -346,7 +357,7 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
         if len(datas) == 1:
             recs = [_process(replica, datas[0], keys, optional_keys, callback_fn, as_half)]
         else:
-            recs = _process_batch(replica, datas, keys, optional_keys, callback_fn, as_half)
+            recs = _process_batch(replica, datas, keys, optional_keys, callback_fn, as_half, view_key)
         return [(idx, name, rec) for (idx, _), name, rec in zip(chunk, names, recs)]
 
     if workers <= 1 or device == "cpu":
@@ -356,7 +367,7 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
             for chunk in _batches(indexed, pair_batch):
                 datas = [_to_device(d, device) for _, d in chunk]
                 names = [d.get("name", [None])[0] for d in datas]
-                fin = _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half)
+                fin = _process_batch_async(model, datas, keys, optional_keys, callback_fn, as_half, view_key)
                 if pending is not None:
                     out.extend((idx, name, rec) for (idx, _), name, rec in zip(pending[0], pending[1], pending[2]()))
                 pending = (chunk, names, fin)

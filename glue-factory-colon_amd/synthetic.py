@@ -38,19 +38,22 @@ def synthetic_pairs(n_pairs: int, height: int = 480, width: int = 640, seed: int
 HPATCHES_LIKE_SHAPES = [(480, 640), (480, 613), (640, 480), (725, 480), (480, 656)]  # (h, w): short side 480
 
 
-def hpatches_shaped_pairs(n_pairs: int, seed: int = 4000, device="cpu", per_sequence: int = 5):
+def hpatches_shaped_pairs(n_pairs: int, seed: int = 4000, device="cpu", per_sequence: int = 5, shared_view0: bool = False):
     """`n_pairs` loader items shaped like the HPatches evaluation list (BASELINE config 3; datasets/hpatches.py:94-112:
     RGB, short side resized to 480, arbitrary long side, batch 1, `scales` = new / original size): sequences of
     `per_sequence` pairs share view 0's image shape (the sequence's reference image), view 1's shape changes from item
     to item.  Both views are crops of one band-limited canvas displaced by (24, 16) pixels, so that true
-    correspondences exist."""
+    correspondences exist.  shared_view0: like the real list (datasets/hpatches.py:98-99 reads image 1 of the sequence as
+    view 0 of every one of its five pairs) all pairs of a sequence carry THE SAME view-0 image, and their view 1 is
+    another crop of the sequence's canvas; items then also carry `scene` (the sequence name, as the reference's items do)."""
     items = []
     for i in range(n_pairs):
         s0 = HPATCHES_LIKE_SHAPES[(i // per_sequence) % len(HPATCHES_LIKE_SHAPES)]
         s1 = HPATCHES_LIKE_SHAPES[(i * 2 + 1) % len(HPATCHES_LIKE_SHAPES)]
-        canvas = synthetic_images(1, 760, 680, seed=seed + i)[0, 0]
+        canvas = synthetic_images(1, 760, 680, seed=seed + (i // per_sequence if shared_view0 else i))[0, 0]
+        off1 = (16 + 4 * (i % per_sequence), 24 + 6 * (i % per_sequence)) if shared_view0 else (16, 24)
         views = {}
-        for tag, (h, w), (y, x), up in (("view0", s0, (0, 0), 2.0), ("view1", s1, (16, 24), 1.5)):
+        for tag, (h, w), (y, x), up in (("view0", s0, (0, 0), 2.0), ("view1", s1, off1, 1.5)):
             g = canvas[y:y + h, x:x + w]
             rgb = torch.stack([g * 0.8, g, g * 0.9], 0).clamp(0, 1)
             rgb = ((rgb * 255).round() / 255).float()[None]  # what a decoded uint8 image gives
@@ -58,7 +61,8 @@ def hpatches_shaped_pairs(n_pairs: int, seed: int = 4000, device="cpu", per_sequ
             views[tag] = {"image": rgb.to(device), "image_size": torch.tensor([[float(w), float(h)]], device=device),
                           "scales": torch.tensor([[w / ow, h / oh]], dtype=torch.float32, device=device),
                           "original_image_size": torch.tensor([[float(ow), float(oh)]], device=device)}
-        items.append({"name": [f"synth{i // per_sequence}/{i % per_sequence + 2}.ppm"], **views})
+        items.append({"name": [f"synth{i // per_sequence}/{i % per_sequence + 2}.ppm"], "scene": [f"synth{i // per_sequence}"],
+                      **views})
     return items
 
 

@@ -152,14 +152,18 @@ class TwoViewPipeline(BaseModel):
         pred["pair_resolution"] = full(image0.shape[-2] * image0.shape[-1] + image1.shape[-2] * image1.shape[-1])
         return pred
 
-    def forward_pairs(self, datas):
+    def forward_pairs(self, datas, view_keys=None):
         """MI355X addition: `[self(d) for d in datas]` for batch-1 pairs whose IMAGES DIFFER IN SIZE (the HPatches
         evaluation list: datasets/hpatches.py:60 asserts batch size 1, utils/export_predictions.py:36-45 runs the model
         pair by pair) with both stages batched: the extractor once per distinct image shape among the 2N views
         (`forward_views`), the matcher ONCE over all N pairs with their own key-point counts (`forward_pairs`,
         gfc_lg_forward_ragged).  Every pair's prediction carries the keys of the single-pair call; the timing /
         memory keys are the batch's figures divided by N (one device-synchronised measurement per stage and batch).
-        Pairs with cached features, batched pairs, or a matcher without `forward_pairs` take `self(d)`."""
+        Pairs with cached features, batched pairs, or a matcher without `forward_pairs` take `self(d)`.
+        view_keys (optional): one (key0, key1) per pair; views with EQUAL non-None keys are declared by the caller to be
+        the same image and are extracted once (an HPatches sequence reads its reference image as view 0 of all five of its
+        pairs, datasets/hpatches.py:98-99: 32 consecutive pairs hold ~39 distinct images, not 64).  Every pair's
+        prediction is what it is without the keys -- an image's features do not depend on what else is in its batch."""
         ext, mat = getattr(self, "extractor", None), getattr(self, "matcher", None)
         ok = len(datas) > 1 and ext is not None and (mat is None or hasattr(mat, "forward_pairs"))
         for d in datas:
@@ -174,7 +178,26 @@ class TwoViewPipeline(BaseModel):
         views = [d[f"view{i}"] for d in datas for i in ("0", "1")]
         # extractors without `forward_views` (DISK: its own chunked batching) run view by view; the matcher is batched either way
         many = ext.forward_views if hasattr(ext, "forward_views") else (lambda vs: [ext(v) for v in vs])
+        slot = list(range(len(views)))  # view -> index of the extraction that serves it
+        if view_keys is not None:
+            assert len(view_keys) == n, "one (key0, key1) per pair"
+            flat = [k for pair in view_keys for k in pair]
+            first, uniq = {}, []
+            for j, (v, k) in enumerate(zip(views, flat)):
+                if k is not None and k in first:
+                    u = first[k]
+                    if uniq[u]["image"].shape != v["image"].shape:
+                        raise ValueError(f"view key {k!r} names images of different shapes "
+                                         f"{tuple(uniq[u]['image'].shape)} / {tuple(v['image'].shape)}")
+                else:
+                    u = len(uniq)
+                    uniq.append(v)
+                    if k is not None:
+                        first[k] = u
+                slot[j] = u
+            views = uniq
         vpreds, t_ext, mem_ext = self._timed(device, lambda: many(views))
+        vpreds = [dict(vpreds[u]) for u in slot]
         cores = [vp.pop("extractor_core_time_ms", None) for vp in vpreds]
         preds = []
         for j, d in enumerate(datas):

@@ -291,6 +291,42 @@ def test_export_from_host_uint8_images_with_gpu_preprocessing(tmp_path):
            h2d_mb_per_pair=feeder.h2d_bytes / 40 / 1e6)
 
 
+def test_view_dedupe_extracts_a_shared_reference_image_once_and_changes_no_record(tmp_path):
+    """export_predictions(pair_batch=32, view_key=...): on an HPatches-structured list (every pair of a sequence carries
+    the sequence's image 1 as view 0, datasets/hpatches.py:98-99) the views a key function names as the same image are
+    extracted once per pair batch.  40 pairs = 8 sequences: 48 instead of 80 extractions; every record array is
+    bit-identical to the run without keys (an image's features do not depend on the rest of its batch)."""
+    from glue_factory_colon_amd import synthetic
+
+    items = synthetic.hpatches_shaped_pairs(40, seed=6100, shared_view0=True)
+    assert torch.equal(items[0]["view0"]["image"], items[4]["view0"]["image"])
+    assert not torch.equal(items[0]["view0"]["image"], items[5]["view0"]["image"])
+    keys = EXPORT_KEYS + ["keypoint_scores0", "keypoint_scores1"]
+    counts = []
+
+    def counting(pipe):
+        inner = pipe.extractor.forward_views
+        pipe.extractor.forward_views = lambda views: (counts.append(len(views)), inner(views))[1]
+        return pipe
+
+    plain = load_predictions(export_predictions(items, counting(official_pipeline()), tmp_path / "a.npz", keys=keys, pair_batch=32))
+    n_plain = sum(counts)
+    counts.clear()
+    vk = lambda item, i: (item["scene"][0], 1) if i == 0 else None  # noqa: E731
+    dedup = load_predictions(export_predictions(items, counting(official_pipeline()), tmp_path / "b.npz", keys=keys, pair_batch=32,
+                                                view_key=vk))
+    assert n_plain == 80 and sum(counts) == 40 + 7 + 2, (n_plain, counts)  # batch 1: 32 pairs = 7 sequences, batch 2: 8 pairs = 2
+    assert list(plain) == list(dedup) and len(plain) == 40
+    for name in plain:
+        for k in plain[name]:
+            assert np.array_equal(plain[name][k], dedup[name][k]), (name, k)
+    assert sum(int((r["matches0"] >= 0).sum()) for r in plain.values()) > 40 * 100
+    # names that collide on images of different shapes are refused
+    bad = lambda item, i: "same"  # noqa: E731
+    with pytest.raises(ValueError, match="different shapes"):
+        export_predictions(items[:8], official_pipeline(), tmp_path / "c.npz", keys=keys, pair_batch=8, view_key=bad)
+
+
 def test_workers_and_pair_batch_are_not_combinable(tmp_path):
     """Round-5 pruning: `workers` > 1 together with `pair_batch` > 1 is refused (slower than pair_batch alone)."""
     items = hpatches_shaped_list(4)
