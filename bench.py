@@ -303,18 +303,23 @@ def c3_regime(dev, n_pairs: int = 128, n_host: int = 64):
         from glue_factory_colon_amd.image_preprocessor import HostImageFeeder
         # (the 64 distinct pairs are walked four times per pass: the first batch of a pass waits for its own copies, a
         # start-up cost that a 540-pair list amortises and a two-batch pass would not)
-        raw = synthetic.hpatches_like_host_images(n_host) * 4
+        raw = synthetic.hpatches_like_host_images(n_host, shared_view0=True) * 4
         n_host *= 4
         pconf = {"resize": 480, "side": "short"}
+        raw_key = lambda r, i: (r["scene"], 1) if i == 0 else None      # noqa: E731  (names on the RAW items: strings)
+        item_key = lambda d, i: (d["scene"][0], 1) if i == 0 else None  # noqa: E731  (on loader items: lists of one)
         host = {}
-        for tag in ("from_host_uint8_pair_batch32", "resident_same_images_pair_batch32"):
+        for tag in ("from_host_uint8_pair_batch32", "from_host_uint8_pair_batch32_view_dedupe", "resident_same_images_pair_batch32"):
             best, feeder = None, None
+            dedupe = tag.endswith("view_dedupe")
             resident = list(HostImageFeeder(raw, pconf)) if tag.startswith("resident") else None
             for rep in range(3):  # first pass untimed
-                feeder = HostImageFeeder(raw, pconf) if resident is None else None
+                feeder = HostImageFeeder(raw, pconf, view_key=raw_key if dedupe else None) if resident is None else None
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                out = run(pipe, 1, 32, feeder if resident is None else resident)
+                out = []
+                ep._export_loop(enumerate(feeder if resident is None else resident), pipe, "cuda", keys, optional, None, False, 1,
+                                out, 32, item_key if dedupe else None)
                 torch.cuda.synchronize(dev)
                 dt = time.perf_counter() - t0
                 if rep:
@@ -323,12 +328,12 @@ def c3_regime(dev, n_pairs: int = 128, n_host: int = 64):
                          "matches_total": sum(int((rec["matches0"] >= 0).sum()) for _, _, rec in out)}
             if feeder is not None:
                 host[tag]["h2d_mb_per_pair"] = round(feeder.h2d_bytes / n_host / 1e6, 2)
-        host["same_integers"] = host["from_host_uint8_pair_batch32"]["matches_total"] == \
-            host["resident_same_images_pair_batch32"]["matches_total"]
-        host["sample"] = (f"{n_host} pairs ({n_host // 4} distinct, walked four times) of decoded RGB uint8 images at original sizes "
-                          f"{synthetic.HPATCHES_LIKE_ORIGINALS} (pinned host memory), ImagePreprocessor resize 480 / side "
-                          "short on the GPU (HostImageFeeder), then the pair_batch32 export loop; `resident_*` = the "
-                          "same preprocessed images already in HBM")
+        host["same_integers"] = len({v["matches_total"] for v in host.values()}) == 1
+        host["sample"] = (f"{n_host} pairs ({n_host // 4} distinct, walked four times; sequences of five share their view 0 as in the "
+                          f"HPatches list) of decoded RGB uint8 images at original sizes {synthetic.HPATCHES_LIKE_ORIGINALS} (pinned "
+                          "host memory), ImagePreprocessor resize 480 / side short on the GPU (HostImageFeeder), then the pair_batch32 "
+                          "export loop; `view_dedupe` = the shared image is copied, resized and extracted once per occurrence window "
+                          "(view_key on the feeder and on the loop); `resident_*` = the same preprocessed images already in HBM")
         res["from_host_uint8"] = host
     res["same_match_count"] = len({v["matches_total"] for v in legs.values()}) == 1
     res["all_legs_integers_equal"] = all(v["integers_equal_to_first_leg"] for v in legs.values())

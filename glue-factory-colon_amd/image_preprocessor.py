@@ -132,8 +132,12 @@ class HostImageFeeder:
     Yields batch-1 items (`image` [1,C,h,w] float32, `scales` [1,2], `image_size` [1,2], `original_image_size` [1,2],
     `transform` [1,3,3] float64 on the host), i.e. what the reference's DataLoader collates."""
 
-    def __init__(self, raw_items, conf, device="cuda", depth=64, bgr=False):
+    def __init__(self, raw_items, conf, device="cuda", depth=64, bgr=False, view_key=None, keep=16):
+        """view_key (optional): `view_key(raw_item, i) -> hashable or None`, the NAME of the image of view i; a name seen among
+        the last `keep` named images is neither copied nor resized again -- the item gets the tensors of its first occurrence
+        (an HPatches sequence names its image 1 as view 0 of all five of its pairs, datasets/hpatches.py:98-99)."""
         self.raw, self.pre, self.depth, self.bgr = raw_items, ImagePreprocessor(conf), max(1, int(depth)), bool(bgr)
+        self.view_key, self.keep, self._named = view_key, max(1, int(keep)), {}
         if self.pre.conf["square_pad"]:
             raise NotImplementedError("square_pad on the host-image path")
         if self.pre.conf["interpolation"] != "bilinear":
@@ -147,7 +151,12 @@ class HostImageFeeder:
     def _stage(self, raw, copy_stream, slot):
         """Issue the copies of one item on the copy stream; returns what `_finish` needs."""
         views, meta, srcs = {}, [], []
-        for tag in ("view0", "view1"):
+        for i, tag in enumerate(("view0", "view1")):
+            key = self.view_key(raw, i) if self.view_key is not None else None
+            if key is not None and key in self._named:
+                views[tag] = self._named[key]  # the first occurrence's record: filled by ITS _finish, which runs before ours
+                meta += [0.0] * 6
+                continue
             u8 = raw[tag]["image"]
             if u8.dtype != torch.uint8 or u8.ndim not in (2, 3):
                 raise ValueError(f"{tag}: expected a decoded uint8 image [H,W,C] or [H,W], got {u8.dtype} {tuple(u8.shape)}")
@@ -155,7 +164,7 @@ class HostImageFeeder:
             size = (h, w) if self.pre.conf["resize"] is None else tuple(self.pre.get_new_image_size(h, w))
             # torch.Tensor([new_w / w, new_h / h]) (image.py:49): python floats rounded to fp32
             meta += [size[1] / w, size[0] / h, float(size[1]), float(size[0]), float(w), float(h)]
-            srcs.append((tag, u8, size, (h, w)))
+            srcs.append((tag, u8, size, (h, w), key))
             self.h2d_bytes += u8.numel()
         # the item's 12 numbers go through a slot of a pinned ring (allocated once); a slot comes round again after
         # `depth` + 1 items, when its copy has long completed (checked: the event is synchronised, which returns at once)
@@ -164,8 +173,13 @@ class HostImageFeeder:
             events[slot].synchronize()
         ring[slot] = torch.tensor(meta, dtype=torch.float32)
         with torch.cuda.stream(copy_stream):
-            for tag, u8, size, hw in srcs:
-                views[tag] = (u8.to(self.device, non_blocking=True), size, hw)
+            for tag, u8, size, hw, key in srcs:
+                rec = {"dev": u8.to(self.device, non_blocking=True), "size": size, "hw": hw, "out": None}
+                views[tag] = rec
+                if key is not None:
+                    self._named[key] = rec
+                    while len(self._named) > self.keep:
+                        self._named.pop(next(iter(self._named)))  # oldest name first (insertion order)
             dev_meta = ring[slot].to(self.device, non_blocking=True)
             done = torch.cuda.Event()
             done.record(copy_stream)
@@ -177,23 +191,26 @@ class HostImageFeeder:
         main = torch.cuda.current_stream(self.device)
         main.wait_event(done)
         dev_meta.record_stream(main)
-        item = {k: v for k, v in raw.items() if k not in ("view0", "view1")}
-        if isinstance(item.get("name"), str):
-            item["name"] = [item["name"]]  # as collated by the DataLoader
+        # strings as the DataLoader collates them: lists of one
+        item = {k: ([v] if isinstance(v, str) else v) for k, v in raw.items() if k not in ("view0", "view1")}
         for j, tag in enumerate(("view0", "view1")):
-            dev, size, (h, w) = views[tag]
-            dev.record_stream(main)
-            conf = self.pre.conf
-            if conf["resize"] is not None:
-                img = resize(dev, size, conf["align_corners"], conf["antialias"], bgr=self.bgr)
-            else:
-                img = resize(dev, size, None, False, bgr=self.bgr)  # conversion only
-            m = dev_meta[6 * j: 6 * j + 6]
-            sx, sy = size[1] / w, size[0] / h
+            rec = views[tag]
+            if rec["out"] is None:  # first (or only) occurrence of this image: convert + resize now
+                dev, size, (h, w) = rec["dev"], rec["size"], rec["hw"]
+                dev.record_stream(main)
+                conf = self.pre.conf
+                if conf["resize"] is not None:
+                    img = resize(dev, size, conf["align_corners"], conf["antialias"], bgr=self.bgr)
+                else:
+                    img = resize(dev, size, None, False, bgr=self.bgr)  # conversion only
+                m = dev_meta[6 * j: 6 * j + 6]
+                sx, sy = size[1] / w, size[0] / h
+                rec["out"] = {"image": img[None], "scales": m[0:2][None], "image_size": m[2:4][None],
+                              "original_image_size": m[4:6][None],
+                              "transform": torch.from_numpy(np.diag([np.float32(sx), np.float32(sy), 1.0]))[None]}
+                rec["dev"] = None  # the bytes are not needed any more
             extra = {k: v for k, v in raw[tag].items() if k != "image"}
-            item[tag] = {**extra, "image": img[None], "scales": m[0:2][None], "image_size": m[2:4][None],
-                         "original_image_size": m[4:6][None],
-                         "transform": torch.from_numpy(np.diag([np.float32(sx), np.float32(sy), 1.0]))[None]}
+            item[tag] = {**extra, **rec["out"]}
         return item
 
     def __iter__(self):
@@ -206,6 +223,7 @@ class HostImageFeeder:
         return zip(idx, self._iterate(self.raw[i] for i in idx))
 
     def _iterate(self, raw_iterable):
+        self._named = {}
         copy_stream = torch.cuda.Stream(self.device)
         ring = self.depth + 1
         self._meta_ring = (torch.empty((ring, 12), dtype=torch.float32).pin_memory(), [None] * ring)

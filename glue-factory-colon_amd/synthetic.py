@@ -71,23 +71,32 @@ def hpatches_shaped_pairs(n_pairs: int, seed: int = 4000, device="cpu", per_sequ
 HPATCHES_LIKE_ORIGINALS = [(960, 1280), (960, 1226), (1280, 960), (1088, 720), (720, 984)]
 
 
-def hpatches_like_host_images(n_pairs: int, seed: int = 4000, per_sequence: int = 5, pin: bool = True):
+def hpatches_like_host_images(n_pairs: int, seed: int = 4000, per_sequence: int = 5, pin: bool = True,
+                              shared_view0: bool = False):
     """`n_pairs` RAW loader items as the HPatches dataset holds them right after decoding (datasets/hpatches.py:94-96:
     cv2.imread -> RGB uint8 [H,W,3]), at original sizes HPATCHES_LIKE_ORIGINALS, in (pinned) host memory: the input of
     image_preprocessor.HostImageFeeder.  Same sequence structure and image content as `hpatches_shaped_pairs` (the
-    band-limited canvas is up-sampled bicubically to the original size and quantised to bytes)."""
+    band-limited canvas is up-sampled bicubically to the original size and quantised to bytes).  shared_view0: the five pairs
+    of a sequence carry the same view-0 image (one tensor), as in the real list; items then carry `scene`."""
     items = []
+    ref_view = {}
     for i in range(n_pairs):
         j0 = (i // per_sequence) % len(HPATCHES_LIKE_SHAPES)
         j1 = (i * 2 + 1) % len(HPATCHES_LIKE_SHAPES)
-        canvas = synthetic_images(1, 760, 680, seed=seed + i)[0, 0]
+        canvas = synthetic_images(1, 760, 680, seed=seed + (i // per_sequence if shared_view0 else i))[0, 0]
+        off1 = (16 + 4 * (i % per_sequence), 24 + 6 * (i % per_sequence)) if shared_view0 else (16, 24)
         views = {}
-        for tag, j, (y, x) in (("view0", j0, (0, 0)), ("view1", j1, (16, 24))):
+        for tag, j, (y, x) in (("view0", j0, (0, 0)), ("view1", j1, off1)):
+            if shared_view0 and tag == "view0" and i // per_sequence in ref_view:
+                views[tag] = {"image": ref_view[i // per_sequence]}
+                continue
             h, w = HPATCHES_LIKE_SHAPES[j]
             oh, ow = HPATCHES_LIKE_ORIGINALS[j]
             g = F.interpolate(canvas[None, None, y:y + h, x:x + w], size=(oh, ow), mode="bicubic", align_corners=False)[0, 0]
             rgb = torch.stack([g * 0.8, g, g * 0.9], -1).clamp(0, 1)
             u8 = (rgb * 255).round().to(torch.uint8).contiguous()
             views[tag] = {"image": u8.pin_memory() if pin else u8}
-        items.append({"name": f"synth{i // per_sequence}/{i % per_sequence + 2}.ppm", **views})
+            if shared_view0 and tag == "view0":
+                ref_view[i // per_sequence] = views[tag]["image"]
+        items.append({"name": f"synth{i // per_sequence}/{i % per_sequence + 2}.ppm", "scene": f"synth{i // per_sequence}", **views})
     return items

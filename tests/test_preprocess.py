@@ -135,3 +135,31 @@ def test_host_image_feeder_items_and_round_robin_shard():
     assert [i for i, _ in share] == [1, 4]
     for i, it in share:
         assert torch.equal(it["view0"]["image"], items[i]["view0"]["image"]) and it["name"] == items[i]["name"]
+
+
+@pytest.mark.gpu
+def test_host_image_feeder_copies_and_resizes_a_named_image_once():
+    """HostImageFeeder(view_key=...): an image named again within the last `keep` names is neither copied nor resized a second
+    time -- its items share the first occurrence's tensors; the items equal those of the feeder without names."""
+    from glue_factory_colon_amd.image_preprocessor import HostImageFeeder
+
+    ref_img = [_img(96, 128, 3, seed=70 + s) for s in range(3)]
+    raw = [{"name": f"s{i // 3}/{i % 3 + 2}.ppm", "scene": f"s{i // 3}", "view0": {"image": ref_img[i // 3]},
+            "view1": {"image": _img(90 + i, 120, 3, seed=80 + i)}} for i in range(9)]
+    conf = {"resize": 64, "side": "short"}
+    plain = list(HostImageFeeder(raw, conf, depth=4))
+    feeder = HostImageFeeder(raw, conf, depth=4, view_key=lambda r, i: (r["scene"], 1) if i == 0 else None)
+    named = list(feeder)
+    total = sum(r[v]["image"].numel() for r in raw for v in ("view0", "view1"))
+    assert feeder.h2d_bytes == total - 6 * ref_img[0].numel()  # two of the three occurrences of each reference image skipped
+    for i, (a, b) in enumerate(zip(plain, named)):
+        assert a["name"] == b["name"] == [raw[i]["name"]] and b["scene"] == [raw[i]["scene"]]
+        for v in ("view0", "view1"):
+            for k in ("image", "scales", "image_size", "original_image_size"):
+                assert torch.equal(a[v][k], b[v][k]), (i, v, k)
+    assert named[0]["view0"]["image"].data_ptr() == named[2]["view0"]["image"].data_ptr()
+    assert named[0]["view0"]["image"].data_ptr() != named[3]["view0"]["image"].data_ptr()
+    # `keep` bounds the window: with keep = 1 a name is forgotten once another named image has passed
+    f1 = HostImageFeeder(raw[:4], conf, view_key=lambda r, i: (r["scene"], i), keep=1)
+    list(f1)
+    assert f1.h2d_bytes == sum(r[v]["image"].numel() for r in raw[:4] for v in ("view0", "view1"))
