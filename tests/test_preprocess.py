@@ -160,6 +160,6 @@ def test_host_image_feeder_copies_and_resizes_a_named_image_once():
     assert named[0]["view0"]["image"].data_ptr() == named[2]["view0"]["image"].data_ptr()
     assert named[0]["view0"]["image"].data_ptr() != named[3]["view0"]["image"].data_ptr()
     # `keep` bounds the window: with keep = 1 a name is forgotten once another named image has passed
-    f1 = HostImageFeeder(raw[:4], conf, view_key=lambda r, i: (r["scene"], i), keep=1)
+    f1 = HostImageFeeder(raw[:4], conf, view_key=lambda r, i: (r["scene"], 0) if i == 0 else r["name"], keep=1)
     list(f1)
     assert f1.h2d_bytes == sum(r[v]["image"].numel() for r in raw[:4] for v in ("view0", "view1"))
