@@ -175,7 +175,7 @@ def _record(pred, data, keys, optional_keys, callback_fn, as_half, to_host=True)
     return rec
 
 
-def _sharded(loader, rank, world):
+def _sharded(loader, rank, world, group=1):
     """(index, item) of this rank's round-robin share of the loader (sharding.round_robin_shard: pairs of an
     HPatches-style list differ in size, so consecutive pairs go to different ranks).  A loader that can skip work
     itself may offer `shard(rank, world)` yielding (index, item); a sequential batch-1 torch DataLoader (what the
@@ -185,11 +185,11 @@ def _sharded(loader, rank, world):
     if world <= 1:
         yield from enumerate(loader)
     elif hasattr(loader, "shard"):
-        yield from loader.shard(rank, world)
+        yield from (loader.shard(rank, world, group) if group > 1 else loader.shard(rank, world))
     elif (isinstance(loader, DataLoader) and loader.batch_size == 1 and isinstance(loader.sampler, SequentialSampler)
           and hasattr(loader.dataset, "__len__") and hasattr(loader.dataset, "__getitem__")):
         from .sharding import round_robin_shard
-        idx = list(round_robin_shard(len(loader.dataset), rank, world))
+        idx = list(round_robin_shard(len(loader.dataset), rank, world, group))
         extra = {"timeout": loader.timeout, "generator": loader.generator}
         if loader.num_workers > 0:  # only valid with worker processes
             extra.update(prefetch_factor=loader.prefetch_factor, persistent_workers=loader.persistent_workers,
@@ -200,11 +200,11 @@ def _sharded(loader, rank, world):
         yield from zip(idx, sub)
     elif hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
         from .sharding import round_robin_shard
-        for i in round_robin_shard(len(loader), rank, world):
+        for i in round_robin_shard(len(loader), rank, world, group):
             yield i, loader[i]
     else:
         for i, item in enumerate(loader):
-            if i % world == rank:
+            if (i // max(group, 1)) % world == rank:
                 yield i, item
 
 
@@ -259,12 +259,14 @@ def _decode_blocks(blocks):
 
 @torch.no_grad()
 def export_predictions(loader, model, output_file, as_half=False, keys="*", callback_fn=None, optional_keys=(),
-                       workers=1, rank=None, world=None, pair_batch=1, view_key=None):
+                       workers=1, rank=None, world=None, pair_batch=1, view_key=None, shard_group=1):
     """pair_batch: number of consecutive pairs processed by one `model.forward_pairs` call (module docstring).
     view_key (with pair_batch > 1): `view_key(item, i) -> hashable or None` names the image of view i of a loader item;
     views of one pair batch with equal non-None names are extracted ONCE (TwoViewPipeline.forward_pairs).  For the
     HPatches list (datasets/hpatches.py:98-112: view 0 of every pair of a sequence is the sequence's image 1):
     `view_key=lambda item, i: (item["scene"][0], 1) if i == 0 else None`.  Records are unchanged.
+    shard_group: under torch.distributed the list is dealt out round-robin `shard_group` consecutive items at a time
+    (5 keeps an HPatches sequence, whose pairs share their view 0, together on one rank: what `view_key` needs).
     rank / world (default: the torch.distributed process group, if one is initialised): the pair list is shared
     out round-robin over the ranks (one process per GPU, no data-path collective); at the end ONE gather brings every
     rank's records to rank 0 (RCCL over xGMI: one direct peer write per rank), which writes the single
@@ -285,7 +287,7 @@ def export_predictions(loader, model, output_file, as_half=False, keys="*", call
         failure = None
         local = []
         try:
-            _export_loop(_sharded(loader, rank, world), model, device, keys, optional_keys, callback_fn, as_half,
+            _export_loop(_sharded(loader, rank, world, int(shard_group)), model, device, keys, optional_keys, callback_fn, as_half,
                          workers, local, pair_batch, view_key)
         except Exception as e:  # noqa: BLE001 -- re-raised below, after the other ranks have been told
             failure = e

@@ -216,10 +216,11 @@ class HostImageFeeder:
     def __iter__(self):
         return self._iterate(self.raw)
 
-    def shard(self, rank, world):
-        """(index, item) of this rank's round-robin share (export_predictions' sharded mode, sharding.round_robin_shard):
-        only this rank's images are copied and resized."""
-        idx = range(int(rank), len(self.raw), int(world))
+    def shard(self, rank, world, group=1):
+        """(index, item) of this rank's round-robin share (export_predictions' sharded mode, sharding.round_robin_shard:
+        `group` consecutive items at a time): only this rank's images are copied and resized."""
+        from .sharding import round_robin_shard
+        idx = round_robin_shard(len(self.raw), int(rank), int(world), int(group))
         return zip(idx, self._iterate(self.raw[i] for i in idx))
 
     def _iterate(self, raw_iterable):

@@ -38,8 +38,12 @@ def contiguous_shard(n_items: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < extra else 0))
 
 
-def round_robin_shard(n_items: int, rank: int, world: int) -> range:
-    return range(rank, n_items, world)
+def round_robin_shard(n_items: int, rank: int, world: int, group: int = 1):
+    """Items dealt out round-robin, `group` consecutive items at a time (group 5 keeps the five pairs of an HPatches
+    sequence -- which share their view-0 image -- on one rank, next to each other)."""
+    if group <= 1:
+        return range(rank, n_items, world)
+    return [i for i in range(n_items) if (i // group) % world == rank]
 
 
 def gather_records(records: torch.Tensor, dst: int = 0) -> Optional[List[torch.Tensor]]:

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_contract():
     # (--no-batch1: without the information-only legs `batch1` / `c3_regime` / `c4` / `config5`, which are best-effort
-    # objects behind try / except -- tools/profile_r04.sh runs the full line; this test keeps the GPU suite short)
+    # objects behind try / except -- tools/profile_r05.sh runs the full line; this test keeps the GPU suite short)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-iters", "1", "--cpu-pairs", "1",
                         "--no-batch1"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)

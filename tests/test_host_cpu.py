@@ -155,6 +155,10 @@ def test_shard_partitions():
         assert max(map(len, blocks)) - min(map(len, blocks)) <= 1
         rr = [list(sharding.round_robin_shard(n, r, w)) for r in range(w)]
         assert sorted(sum(rr, [])) == list(range(n))
+        g5 = [list(sharding.round_robin_shard(n, r, w, 5)) for r in range(w)]  # whole groups of five per rank
+        assert sorted(sum(g5, [])) == list(range(n))
+        assert all(len({i // 5 for i in chunk}) * 5 >= len(chunk) for chunk in g5)
+        assert all(i // 5 % w == r for r, chunk in enumerate(g5) for i in chunk)
 
 
 def _free_port():
@@ -531,6 +535,13 @@ def test_export_predictions_sharded_world8_gloo_540_items(tmp_path):
         "        assert int(r['who'][0]) == i % world\n"
         "        assert np.array_equal(r['keypoints0'], (it['view0']['x'][0] * (1.0 / it['view0']['scales'])).numpy())\n"
         "    print('WORLD8_EXPORT_OK')\n"
+        "torch.distributed.barrier()\n"
+        "seen.clear()\n"
+        "export_predictions(items, Fake(), out + '/g.npz', keys=['keypoints0', 'matches0', 'who'], pair_batch=5, shard_group=5)\n"
+        "assert seen == [i for i in range(540) if (i // 5) % world == rank], (rank, seen[:12])  # whole sequences per rank\n"
+        "if rank == 0:\n"
+        "    b = load_predictions(out + '/g.npz')\n"
+        "    assert list(b) == list(a) and all(np.array_equal(a[n]['keypoints0'], b[n]['keypoints0']) for n in a)\n"
         "torch.distributed.barrier()\n"
         "seen.clear(); Fake.fail = True\n"
         "try:\n"
