@@ -399,4 +399,4 @@ def run(n_cases=60, seed=2024):
     return failures + bad
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60) else 0)
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 60, int(sys.argv[2]) if len(sys.argv) > 2 else 2024) else 0)
