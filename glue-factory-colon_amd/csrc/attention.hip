@@ -85,7 +85,13 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
     const int qc = min(q[t], nq - 1);
     const float* qp = Q + (size_t)(q_row0 + qc) * ldq + head * AD + 4 * h;
 #pragma unroll
-    for (int g = 0; g < 8; ++g) qf[t][g] = *reinterpret_cast<const float4*>(qp + 8 * g);
+    for (int g = 0; g < 8; ++g) {
+      // scale * log2(e) folded into the query fragment once (round 5): the scores then come out of the matrix pipe in
+      // the soft-max's own units and the per-element multiply in front of every v_exp_f32 is gone -- on this part every
+      // VALU instruction costs the fp32 matrix pipe its issue cycles (tools/micro/mfma_valu_hybrid.hip)
+      const float4 qv = *reinterpret_cast<const float4*>(qp + 8 * g);
+      qf[t][g] = make_float4(qv.x * scale_log2e, qv.y * scale_log2e, qv.z * scale_log2e, qv.w * scale_log2e);
+    }
   }
 
   f32x16 o[QT][2];
@@ -189,11 +195,11 @@ __global__ __launch_bounds__(64 * AW, AW == 4 ? 2 : 1) void attention_kernel(con
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[t][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run[t], mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run[t] - m_new) * scale_log2e);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[t] - m_new);
         float rs = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          s[t][r] = __builtin_amdgcn_exp2f((s[t][r] - m_new) * scale_log2e);  // raw v_exp_f32
+          s[t][r] = __builtin_amdgcn_exp2f(s[t][r] - m_new);  // raw v_exp_f32 (scores already in log2 units)
           rs += s[t][r];
         }
         rs += __shfl_xor(rs, 32);
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const float* __res
   float acc = 0.f, l = 0.f;
   for (int s = 0; s < ksplit; ++s) {
     const float ms = pp[s * 66 + 64];
-    const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((ms - m) * scale_log2e);
+    const float w = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - m);  // (partials carry the maximum in log2 units)
     acc += w * pp[s * 66 + lane];
     l += w * pp[s * 66 + 65];
   }
