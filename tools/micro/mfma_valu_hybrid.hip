@@ -24,11 +24,21 @@ __device__ __forceinline__ void valu_op(v2f& c, v2f x, v2f y) {
   else if constexpr (KIND == 5) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(c) : "v"(x));
   else if constexpr (KIND == 6) asm volatile("v_max_f32 %0, %1, %0" : "+v"(c.x) : "v"(x.x));
   else if constexpr (KIND == 7) asm volatile("v_cndmask_b32 %0, %1, %0, vcc" : "+v"(c.x) : "v"(x.x));
-  else asm volatile("v_and_b32 %0, %1, %0" : "+v"(c.x) : "v"(x.x));
+  else if constexpr (KIND == 8) asm volatile("v_and_b32 %0, %1, %0" : "+v"(c.x) : "v"(x.x));
+  else if constexpr (KIND == 9) asm volatile("ds_read_b32 %0, %1" : "=v"(c.x) : "v"(__builtin_amdgcn_mbcnt_lo(~0u, 0u) * 4u) : "memory");
+  else if constexpr (KIND == 10) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 t;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(__builtin_amdgcn_mbcnt_lo(~0u, 0u) * 16u) : "memory");
+    c.x = t.x;
+  } else asm volatile("s_nop 0");
 }
 
 template <int V, bool MFMA, int KIND = 0>
 __global__ __launch_bounds__(256, 2) void hybrid_loop(float* out, unsigned long long* clk, int iters, float a0, float b0) {
+  __shared__ float lds_dummy[4096];
+  if (threadIdx.x < 64) lds_dummy[threadIdx.x] = a0;
+  __syncthreads();
   f32x16 acc[4];
   for (int t = 0; t < 4; ++t)
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -83,7 +93,7 @@ static void run(int cus) {
   const double waves = (double)grid * 4, per_iter_mfma = MFMA ? 4 * 4096.0 : 0.0, per_iter_valu = 4.0 * V * 256.0;
   const double tf_m = waves * iters * per_iter_mfma / (last * 1e-3) / 1e12, tf_v = waves * iters * per_iter_valu / (last * 1e-3) / 1e12;
   static const char* names[] = {"v_pk_fma_f32", "v_fma_f32", "v_add_f32", "v_mov_b32", "v_exp_f32", "v_pk_add_f32", "v_max_f32",
-                                "v_cndmask_b32", "v_and_b32"};
+                                "v_cndmask_b32", "v_and_b32", "ds_read_b32", "ds_read_b128", "s_nop"};
   // cycles per loop iteration and SIMD (two waves per SIMD): what the 4 MFMAs alone would take is 2 x 4 x 64 = 512
   const double cyc = last * 1e-3 * ghz * 1e9 / iters;
   printf("mfma %d + %2d x %-13s per mfma: matrix %6.1f TFLOP/s (+ vector %6.1f if FMA), %.0f cycles per 4-MFMA iteration and SIMD "
@@ -112,5 +122,8 @@ int main() {
   run<8, true, 7>(cus);
   run<8, true, 8>(cus);
   run<8, true, 4>(cus);
+  run<8, true, 9>(cus);   // LDS instructions (results waited for at the end of the loop body by the compiler's s_waitcnt)
+  run<8, true, 10>(cus);
+  run<8, true, 11>(cus);  // s_nop: pure issue slots
   return 0;
 }
