@@ -11,6 +11,8 @@ two-pass assignment tail); smaller test batches never reach them.  Checked here:
     the attention keys over workgroups, so floats may differ in the last bits there).
 Reference: gluefactory/models/matchers/lightglue.py:422-553, extractors/superpoint_open.py:126-232.
 """
+import os
+
 import pytest
 import torch
 
@@ -23,7 +25,10 @@ from parity_utils import compare_keypoints, match_pairs, record  # noqa: E402
 
 DEV = "cuda"
 H, W, K, B = 480, 640, 1024, 32
-ORACLE_PAIRS = tuple(range(B))  # every pair of the benchmarked batch (the CPU oracle does ~1.6 pairs/s: ~20 s)
+# every pair of the benchmarked batch (the CPU oracle does ~0.4 pairs/s on the GPU box's host share: ~90 s); a child run
+# of this test under another build of the library (test_exact_erf_build_...) checks a spread of four
+_N_ORACLE = int(os.environ.get("GFC_TEST_ORACLE_PAIRS", B))
+ORACLE_PAIRS = tuple(range(B)) if _N_ORACLE >= B else tuple(sorted({round(i * (B - 1) / max(_N_ORACLE - 1, 1)) for i in range(_N_ORACLE)}))
 
 
 def run_batch(ext, mat, v0, v1):
