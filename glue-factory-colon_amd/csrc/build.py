@@ -24,6 +24,17 @@ HEADERS = ["common.h", "runtime.h", os.path.join(PKG, "..", "include", "gfc_amd.
 LIB = os.path.join(PKG, "libgfc_amd.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 VERSION_UNIT = "api.hip"  # compiled with -DGFC_SOURCE_HASH="<hash>": gfc_version() reports it
+# Second builds of the same library with other arithmetic, for the tests that bound a deliberate approximation
+# (GFC_AMD_LIB=<path> selects one): name -> (extra flags, the translation units those flags change; every other
+# object is shared with the default build).
+VARIANTS = {
+    # GELU through the exact erf chain instead of Abramowitz & Stegun 7.1.26 (common.h: gfc_gelu)
+    "exact_erf": (["-DGFC_EXACT_ERF=1"], ["gemm.hip", "lg_misc.hip"]),
+}
+
+
+def variant_lib(name):
+    return os.path.join(PKG, f"libgfc_amd_{name}.so")
 
 
 def _hipcc():
@@ -108,6 +119,33 @@ def build(force=False, verbose=True):
         print(f"gfc build: source hash {whole}; compiled {len(jobs)} of {len(SOURCES)} translation units "
               f"({'forced' if force else 'content hash changed or object missing'}), "
               f"{'linked' if relink else 'library up to date'}", file=sys.stderr)
+    for name, (vflags, vunits) in VARIANTS.items():
+        vdir = os.path.join(objdir, name)
+        os.makedirs(vdir, exist_ok=True)
+        vjobs = []
+        for u in vunits:
+            src, obj = os.path.join(HERE, u), os.path.join(vdir, u.replace(".hip", ".o"))
+            want = _unit_hash(src, vflags)
+            if force or not os.path.exists(obj) or not _stamp_matches(obj + ".sha256", want):
+                vjobs.append((src, obj, vflags, want))
+        for (src, obj, _, want), r in map(compile_one, vjobs):
+            if r.returncode:
+                print(r.stderr, file=sys.stderr)
+                raise RuntimeError(f"hipcc failed on {src} ({name})")
+            with open(obj + ".sha256", "w") as f:
+                f.write(want)
+        vobjs = [os.path.join(vdir if s in vunits else objdir, s.replace(".hip", ".o")) for s in SOURCES]
+        vstamp = os.path.join(vdir, "lib.sha256")
+        if relink or vjobs or not os.path.exists(variant_lib(name)) or not _stamp_matches(vstamp, whole):
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", variant_lib(name), *vobjs],
+                               capture_output=True, text=True)
+            if r.returncode:
+                print(r.stderr, file=sys.stderr)
+                raise RuntimeError(f"link failed ({name})")
+            with open(vstamp, "w") as f:
+                f.write(whole)
+        if verbose:
+            print(f"gfc build: variant {name}: compiled {len(vjobs)} of {len(vunits)} units", file=sys.stderr)
     return LIB
 
 

@@ -534,7 +534,115 @@ def golden_scale_ori():
          log_assignment=npy(out["log_assignment"]), ref_descriptors0=npy(out["ref_descriptors0"]))
 
 
+# ------------------------------------------- the benchmarked configuration itself (BASELINE configs[1] and [3])
+from bench_inputs import C4_PAIRS, DESC_SAMPLE_ROWS, FP64_DEPTH, FP64_IMAGES, desc_checksum_weights  # noqa: E402
+
+
+def _bench_pipeline(k):
+    conf = {"extractor": {"name": "extractors.superpoint_open", "weights": SPO_PATH, "max_num_keypoints": k,
+                          "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "flash": False,
+                        "depth_confidence": -1, "width_confidence": -1}}
+    pipe = TwoViewPipeline(conf).eval()
+    pipe.matcher.load_state_dict(weights.lightglue_state_dict(0), strict=False)
+    return pipe
+
+
+def _bench_records(pipe, v0, v1, pair_ids, k):
+    """The reference's TwoViewPipeline, batch 1 per pair as the evaluation calls it (two_view_pipeline.py:278-339,
+    export_predictions.py:36-52), on pairs of the benchmark's own synthetic batch."""
+    import hashlib
+    import time
+
+    h, w = v0.shape[-2:]
+    size = torch.tensor([[float(w), float(h)]])
+    wts = desc_checksum_weights()
+    rows = torch.linspace(0, k - 1, DESC_SAMPLE_ROWS).round().long()
+    n = len(pair_ids)
+    out = {"pair_ids": np.asarray(pair_ids, np.int32), "desc_rows": rows.numpy().astype(np.int32),
+           "keypoints": np.zeros((n, 2, k, 2), np.int16), "keypoint_scores": np.zeros((n, 2, k), np.float32),
+           "matches": np.zeros((n, 2, k), np.int32), "matching_scores": np.zeros((n, 2, k), np.float32),
+           "desc_sample": np.zeros((n, 2, DESC_SAMPLE_ROWS, 256), np.float32),
+           "desc_checksum": np.zeros((n, 2, 2, k), np.float32), "image_sha256": []}
+    t0 = time.time()
+    for j, i in enumerate(pair_ids):
+        pred = pipe({"view0": {"image": v0[i:i + 1], "image_size": size}, "view1": {"image": v1[i:i + 1], "image_size": size}})
+        for s in (0, 1):
+            kp = pred[f"keypoints{s}"][0]
+            assert kp.shape == (k, 2), kp.shape  # every image of these workloads has more than k detections
+            out["keypoints"][j, s] = (kp - 0.5).round().short().numpy()  # integer pixel (x, y); key point = pixel + 0.5
+            assert torch.equal(torch.from_numpy(out["keypoints"][j, s]).float() + 0.5, kp)
+            out["keypoint_scores"][j, s] = npy(pred[f"keypoint_scores{s}"][0])
+            out["matches"][j, s] = npy(pred[f"matches{s}"][0]).astype(np.int32)
+            out["matching_scores"][j, s] = npy(pred[f"matching_scores{s}"][0])
+            d = pred[f"descriptors{s}"][0]
+            out["desc_sample"][j, s] = npy(d[rows])
+            out["desc_checksum"][j, s] = npy(wts @ d.T)
+        out["image_sha256"].append(hashlib.sha256(npy(v0[i]).tobytes() + npy(v1[i]).tobytes()).hexdigest())
+        print(f"  pair {i}: {int((pred['matches0'] >= 0).sum())} matches, {time.time() - t0:.0f} s", flush=True)
+    out["image_sha256"] = np.array(out["image_sha256"])
+    return out
+
+
+def golden_c2_batch32():
+    """BASELINE configs[1] at the batch bench.py times: all 32 pairs of `synthetic_pairs(32, 480, 640, seed=1234)`
+    (bench.py rank 0), 1024 key points, through the reference itself."""
+    v0, v1 = synthetic.synthetic_pairs(32, 480, 640, seed=1234)
+    save("c2_batch32", **_bench_records(_bench_pipeline(1024), v0, v1, list(range(32)), 1024))
+
+
+def golden_c4_pairs():
+    """BASELINE configs[3]: four pairs of `synthetic_pairs(32, 1024, 1024, seed=1234)` (bench.py --workload c4, rank 0),
+    2048 key points, through the reference itself."""
+    v0, v1 = synthetic.synthetic_pairs(32, 1024, 1024, seed=1234)
+    save("c4_pairs", **_bench_records(_bench_pipeline(2048), v0, v1, list(C4_PAIRS), 2048))
+
+
+def golden_c2_fp64_order():
+    """What the top-1024 order of the C2 images is in exact arithmetic: the reference's SuperPoint-open module cast to
+    float64 (same fp32 weights, same fp32 images, every product and sum in double) on views 0/1 of pairs 0..7.  Used by
+    tools/order_exactness.py to count how many rank swaps each fp32 evaluation (torch-CPU = the reference, and the HIP
+    convolution variants) has against that order (superpoint_open.py:54-58,156-192)."""
+    v0, v1 = synthetic.synthetic_pairs(32, 480, 640, seed=1234)
+    m = make_spo(max_num_keypoints=FP64_DEPTH, detection_threshold=0.0, nms_radius=3).double()
+    n = FP64_IMAGES // 2
+    kpts = np.zeros((n, 2, FP64_DEPTH, 2), np.int16)
+    scores = np.zeros((n, 2, FP64_DEPTH), np.float64)
+    for i in range(n):
+        for s, v in ((0, v0), (1, v1)):
+            # the module's own forward casts the key points to float32 before grid_sample (superpoint_open.py:176), so
+            # the detection half is driven through its sub-modules and functions, as `_forward` does (:132-192)
+            logits = m.detector(m.backbone(v[i:i + 1].double()))
+            assert logits.dtype == torch.float64
+            heat = torch.softmax(logits, 1)[:, :-1]
+            b, _, h, w = heat.shape
+            heat = heat.permute(0, 2, 3, 1).reshape(b, h, w, 8, 8).permute(0, 1, 3, 2, 4).reshape(b, h * 8, w * 8)
+            heat = ref_spo.batched_nms(heat, 3)
+            heat[:, :4] = -1
+            heat[:, :, :4] = -1
+            heat[:, -4:] = -1
+            heat[:, :, -4:] = -1
+            heat = heat.squeeze(0)
+            idxs = torch.where(heat > 0.0)
+            k_all = torch.stack(idxs[-2:], dim=-1).flip(1)
+            k, sc = ref_spo.select_top_k_keypoints(k_all, heat[idxs], FP64_DEPTH)
+            assert k.shape == (FP64_DEPTH, 2) and sc.dtype == torch.float64
+            kpts[i, s] = k.short().numpy()
+            scores[i, s] = sc.numpy()
+            print(f"  fp64 pair {i} view {s}: min gap in top-1024 {np.min(-np.diff(scores[i, s][:1024])):.3g}", flush=True)
+    save("c2_fp64_order", keypoints=kpts, scores=scores)
+
+
 if __name__ == "__main__":
+    if "--only-c2-batch32" in sys.argv:
+        golden_c2_batch32()
+        sys.exit(0)
+    if "--only-c4-pairs" in sys.argv:
+        golden_c4_pairs()
+        sys.exit(0)
+    if "--only-c2-fp64" in sys.argv:
+        golden_c2_fp64_order()
+        sys.exit(0)
     if "--only-official-pipeline" in sys.argv:
         golden_pipeline_official()
         sys.exit(0)
@@ -567,3 +675,6 @@ if __name__ == "__main__":
     golden_pipeline_official()
     golden_pipeline_official_ragged()
     golden_boat_native()
+    golden_c2_batch32()
+    golden_c4_pairs()
+    golden_c2_fp64_order()

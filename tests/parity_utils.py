@@ -43,7 +43,8 @@ def _key(kp):
 
 def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, tie_tol=2e-6, score_tol=1e-5,
                       desc_tol=1e-4, max_flips=0, swap_tol=5e-6):
-    """kp [N,2], sc [N], desc [N,D] (HIP) vs reference lists.  Returns (idx_mine, idx_ref) of the common points.
+    """kp [N,2], sc [N], desc [N,D] (HIP) vs reference lists (ref_desc None: descriptors are compared by the caller).
+    Returns (idx_mine, idx_ref) of the common points.
     max_flips: key points allowed to differ between the two lists (measured 0 on every case of the suite since round 1;
     a test that ever observes one states its allowance explicitly) -- each must still be EXPLAINED below.
     swap_tol: every ORDER difference must be a near tie: a common point that sits at another rank than in the
@@ -60,7 +61,7 @@ def compare_keypoints(name, kp, sc, desc, ref_kp, ref_sc, ref_desc, radius=4, ti
     n_flip = len(ref) - len(common)
     assert n_flip <= max_flips, f"{name}: {n_flip} of {len(ref)} key points differ"
     s_err = (sc[im] - ref_sc[ir]).abs().max().item() if len(common) else 0.0
-    d_err = (desc[im] - ref_desc[ir]).abs().max().item() if len(common) else 0.0
+    d_err = (desc[im] - ref_desc[ir]).abs().max().item() if len(common) and ref_desc is not None else 0.0
     assert s_err < score_tol, (name, s_err)
     assert d_err < desc_tol, (name, d_err)
     # explain every flip
@@ -94,3 +95,63 @@ def match_pairs(kp0, kp1, m0):
     a = kp0[ok]
     b = kp1[m0[ok]]
     return {(float(x0), float(y0), float(x1), float(y1)) for (x0, y0), (x1, y1) in zip(a.tolist(), b.tolist())}
+
+
+# ------------------------------------------------------------------ benchmark-configuration fixtures (reference-made)
+def image_sha256(v0_i, v1_i):
+    """Hash of one pair's input images (fp32 bytes), as tests/golden/make_golden.py::_bench_records stores it."""
+    import hashlib
+
+    return hashlib.sha256(v0_i.cpu().numpy().tobytes() + v1_i.cpu().numpy().tobytes()).hexdigest()
+
+
+def compare_with_reference_pair(name, g, j, p0, p1, out, i, radius=3, min_matches=500):
+    """Pair `i` of a HIP batch (extractor outputs p0 / p1, matcher outputs `out`) against entry `j` of a fixture that
+    tests/golden/make_golden.py::_bench_records produced by running THE REFERENCE (TwoViewPipeline, batch 1) on the
+    same images: key points (set, scores, rank swaps explained), descriptors (sampled rows in full + two weighted
+    checksums of every row), and matches0 / matches1 / matching_scores0 / 1 INDEX BY INDEX through the key-point
+    correspondence (the two lists hold the same points, a few of them at swapped ranks: parity_utils docstring).
+    Returns (number of reference matches, number of indices compared, worst matching-score error)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from bench_inputs import desc_checksum_weights
+
+    rows = g["desc_rows"].long()
+    wts = desc_checksum_weights()
+    perm = []  # per view: my index -> reference index
+    for side, p in ((0, p0), (1, p1)):
+        kp, sc, de = p["keypoints"][i].cpu(), p["keypoint_scores"][i].cpu(), p["descriptors"][i].cpu()
+        ref_kp = g["keypoints"][j, side].float() + 0.5
+        ref_sc = g["keypoint_scores"][j, side]
+        im, ir = compare_keypoints(f"{name}_view{side}", kp, sc, de, ref_kp, ref_sc, None, radius=radius)
+        assert len(im) == len(ref_kp)  # no flips: the lists are permutations of each other
+        to_ref = torch.empty(len(kp), dtype=torch.long)
+        to_ref[im] = ir
+        perm.append(to_ref)
+        to_mine = torch.empty_like(to_ref)
+        to_mine[to_ref] = torch.arange(len(kp))
+        d_err = (de[to_mine[rows]] - g["desc_sample"][j, side]).abs().max().item()
+        assert d_err < 1e-4, (name, side, d_err)  # north star: descriptors within 1e-4
+        c_err = ((wts @ de.T)[:, to_mine] - g["desc_checksum"][j, side]).abs().max().item()
+        assert c_err < 1e-4, (name, side, c_err)  # every row: |sum_c w_c (d - d_ref)_c| (measured ~1e-6)
+        record(f"{name}_view{side}_desc", sample_err=d_err, checksum_err=c_err)
+    # matches, index by index: reference index r of view s pairs with ref_m[r]; mine must say the same after renaming
+    worst, n_idx, n_ref = 0.0, 0, 0
+    for s, key in ((0, "matches0"), (1, "matches1")):
+        mine = out[key][i].cpu()
+        ref_m = g["matches"][j, s].long()
+        a, b = perm[s], perm[1 - s]
+        renamed = torch.full_like(ref_m, -2)
+        renamed[a] = torch.where(mine >= 0, b[mine.clamp(min=0)], mine)  # mine, in the reference's numbering
+        assert torch.equal(renamed, ref_m), (name, key, int((renamed != ref_m).sum()))
+        ms = torch.empty(len(ref_m))
+        ms[a] = out["matching_scores" + key[-1]][i].cpu()
+        worst = max(worst, (ms - g["matching_scores"][j, s]).abs().max().item())
+        n_idx += len(ref_m)
+        if s == 0:
+            n_ref = int((ref_m >= 0).sum())
+    assert n_ref > min_matches, (name, n_ref)
+    assert worst < 1e-4, (name, worst)  # north star: scores within 1e-4 fp32
+    return n_ref, n_idx, worst

@@ -156,24 +156,22 @@ def test_direct_conv_arithmetic_passes_the_model_parity_tests():
 def test_exact_erf_build_passes_the_parity_tests_and_bounds_the_gelu_approximation(golden, tmp_path):
     """The GELU of the FFN kernels uses a 14-instruction erf (Abramowitz & Stegun 7.1.26, csrc/common.h: gfc_gelu) instead
     of the exact-erf chain the reference's F.gelu evaluates (lightglue.py:143-148): a deliberate approximation on the hot
-    path, kept a MEASURED choice here.  `-DGFC_EXACT_ERF=1` is built through tools/ab_build.sh (hipcc, on this box),
-    the reference-vector test of the matcher and the batch-32 oracle comparison run against that library in a child
-    process, and the difference of the two libraries' matcher outputs on the same input is recorded and bounded."""
+    path, kept a MEASURED choice here.  The `-DGFC_EXACT_ERF=1` build of the library is shipped by `build()`
+    (csrc/build.py VARIANTS -> libgfc_amd_exact_erf.so); the reference-vector test of the matcher and the batch-32
+    comparison with the reference-made fixture run against that library in a child process, and the difference of the
+    two libraries' matcher outputs on the same input is recorded and bounded."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(["bash", os.path.join(root, "tools", "ab_build.sh"), "WORKTREE", "exact_erf", "-DGFC_EXACT_ERF=1"],
-                       capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lib = r.stdout.strip().splitlines()[-1]
-    assert os.path.exists(lib)
-    env = dict(os.environ, GFC_AMD_LIB=lib, GFC_TEST_ORACLE_PAIRS="4")  # (the full 32-pair check runs on the default library)
+    lib = os.path.join(root, "glue-factory-colon_amd", "libgfc_amd_exact_erf.so")
+    assert os.path.exists(lib), "libgfc_amd_exact_erf.so missing: __graft_entry__.build() (csrc/build.py VARIANTS) ships it"
+    env = dict(os.environ, GFC_AMD_LIB=lib)
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_models.py"),
                         os.path.join(here, "test_gpu_batch32.py"), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        "-k", "test_lightglue_golden or test_c2_batch32_vs_oracle"],
+                        "-k", "test_lightglue_golden or test_c2_batch32_vs_reference_fixture"],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0 and "2 passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
     # the same matcher input under both libraries
