@@ -442,6 +442,33 @@ def config5(dev, batch: int = 4, pairs: int = 8, iters: int = 6):
                       "parity of the network unpinned (kornia absent offline: HIP vs the CPU restatement of its published source)"}
 
 
+PER_RANK_FIELDS = ("busy_s", "elapsed_s", "attention_avg_launch_ms", "stem_avg_launch_ms", "probe_tflops",
+                   "probe_shader_clock_ghz", "matches_last_step")
+
+
+def per_rank_table(mine, world, device=None):
+    """One all_gather AFTER the timed region: every rank's own numbers, so that an N > 1 line explains itself (a
+    straggling rank, one GPU clocking lower with eight fp32-MFMA loads on the node, host contention).  `mine` follows
+    PER_RANK_FIELDS.  busy_s = this rank's timed steps up to its own device synchronisation, BEFORE the closing barrier
+    (`elapsed_s` includes the wait for the slowest rank; the job's `value` uses the MAX of it over ranks).
+    Returns (list of per-rank dicts, {field: [min, median, max]})."""
+    t = torch.tensor([float("nan") if v is None else float(v) for v in mine], dtype=torch.float64, device=device)
+    if world > 1:
+        rows = [torch.empty_like(t) for _ in range(world)]
+        torch.distributed.all_gather(rows, t)
+    else:
+        rows = [t]
+    table = [{"rank": r, **{k: (None if v != v else round(v, 5)) for k, v in zip(PER_RANK_FIELDS, row.tolist())}}
+             for r, row in enumerate(rows)]
+    summary = {}
+    for k in PER_RANK_FIELDS:
+        vals = sorted(row[k] for row in table if row[k] is not None)
+        if vals:
+            summary[k] = [vals[0], vals[len(vals) // 2] if len(vals) % 2 else round((vals[len(vals) // 2 - 1] + vals[len(vals) // 2]) / 2, 5),
+                          vals[-1]]
+    return table, summary
+
+
 def host_barrier_group(world):
     """A gloo group for the job's closing barrier (rank 0 spends about a minute on the CPU baseline after the timed region:
     the other ranks wait on the host instead of spinning in an RCCL kernel).  One node only (the bench contract), so the
@@ -572,15 +599,17 @@ def rehearse_cpu(args):
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(0.001)
+        time.sleep(0.001 * (1 + rank))  # rank r is r times slower: the per-rank table must show it
+    busy = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     gathered = sharding.gather_records(sharding.pack_pair_records(pred, K))
+    per_rank, per_rank_summary = per_rank_table([busy, elapsed_local, 0.5 + 0.01 * rank, 5.0, None, None, 10 + rank], world)
     if rank == 0:
         allrec = torch.cat(gathered)
         # like main(): rank 0 times the CPU baseline after the gather while the other ranks wait at the last barrier
@@ -589,6 +618,7 @@ def rehearse_cpu(args):
                           "steps": args.steps, "warmup": args.warmup, "rehearsal": True,
                           "pairs_gathered": int(allrec.shape[0]),
                           "matches_per_rank": [int(v) for v in allrec[::b, 0].tolist()],
+                          "config": {"per_rank": per_rank, "per_rank_summary": per_rank_summary, "rccl_ranks": 0},
                           "cpu_baseline": base}), flush=True)
     if world > 1:
         torch.distributed.barrier(group=host_group)
@@ -689,8 +719,9 @@ def main():
         for _ in range(args.steps):
             p0, p1, pred = step()
         torch.cuda.synchronize(dev)
+        busy = time.perf_counter() - t0  # this rank's own steps; the closing barrier waits for the slowest rank
         barrier()
-        elapsed = time.perf_counter() - t0
+        elapsed_local = elapsed = time.perf_counter() - t0
         ext._runner.trace = None
         mat.trace = None
 
@@ -710,6 +741,19 @@ def main():
     adurs = atrace.durations_ms()
     trace.close()
     atrace.close()
+
+    # what the matrix pipe of THIS rank's GPU sustains right after the timed region (the data-sheet 157.3 TFLOP/s assumes
+    # 2.4 GHz), and every rank's own timings: one all_gather, outside the timed region
+    try:
+        tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
+        nat.check(nat.lib().gfc_probe_mfma_peak(80000, ctypes.byref(tf), ctypes.byref(ghz), nat.stream_ptr(dev)), "probe")
+        probe = {"tflops": round(tf.value, 1), "shader_clock_ghz": round(ghz.value, 3),
+                 "note": "registers-only v_mfma_f32_32x32x2_f32 loop on every SIMD, measured after the timed region"}
+    except Exception as e:  # noqa: BLE001
+        probe = {"tflops": None, "shader_clock_ghz": None, "error": repr(e)[:120]}
+    per_rank, per_rank_summary = per_rank_table(
+        [busy, elapsed_local, sum(adurs) / max(len(adurs), 1), sum(durs) / max(len(durs), 1), probe["tflops"],
+         probe["shader_clock_ghz"], int((pred["matches0"] >= 0).sum())], world, dev)
 
     if rank == 0:
         allrec = torch.cat(gathered)
@@ -823,6 +867,9 @@ def main():
                        "pairs_gathered": n_pairs_total, "extractor_calls_per_step": calls,
                        "final_gather_ms": round(gather_ms, 3),
                        "rccl_ranks": torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       # every rank's own numbers (one all_gather after the timed region): `value` uses the MAX of
+                       # elapsed_s; busy_s excludes the closing barrier's wait for the slowest rank
+                       "per_rank": per_rank, "per_rank_summary": per_rank_summary,
                        # whole path per GPU: direct-arithmetic FLOPs of SURVEY.md 8d (a Winograd / folded implementation
                        # executes fewer), and the FLOPs the matrix pipe really executes
                        "pipeline_algorithmic_tflops": round(value / world * PAIR_FLOPS / 1e12, 2),
@@ -832,14 +879,7 @@ def main():
                                                   if exec_pair_flops else None)},
             "roofline": roof,
         }
-        try:  # what the matrix pipe of THIS box sustains (the data-sheet 157.3 TFLOP/s assumes 2.4 GHz): context only
-            tf, ghz = ctypes.c_float(0), ctypes.c_float(0)
-            nat.check(nat.lib().gfc_probe_mfma_peak(80000, ctypes.byref(tf), ctypes.byref(ghz), nat.stream_ptr(dev)), "probe")
-            out["roofline"]["sustained_mfma_probe"] = {
-                "tflops": round(tf.value, 1), "shader_clock_ghz": round(ghz.value, 3),
-                "note": "registers-only v_mfma_f32_32x32x2_f32 loop on every SIMD, measured after the timed region"}
-        except Exception as e:  # noqa: BLE001
-            out["roofline"]["sustained_mfma_probe"] = {"tflops": None, "error": repr(e)[:120]}
+        out["roofline"]["sustained_mfma_probe"] = probe  # rank 0's; every rank's is in config.per_rank
         if args.workload == "c2" and not args.no_self_check:
             try:
                 out["self_check"] = self_check(v0, v1, p0, p1, pred)

@@ -496,6 +496,18 @@ def test_bench_multiprocess_plumbing_rehearsal_world8():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["pairs_gathered"] == 256  # BASELINE configs[3]: 256 pairs over 8 GPUs
     assert out["matches_per_rank"] == [10 + r for r in range(8)]
+    # the line explains itself: every rank's own timings, gathered after the timed region (bench.py::per_rank_table)
+    per = out["config"]["per_rank"]
+    assert [row["rank"] for row in per] == list(range(8))
+    for field in ("busy_s", "elapsed_s", "attention_avg_launch_ms", "stem_avg_launch_ms", "probe_tflops",
+                  "probe_shader_clock_ghz", "matches_last_step"):
+        assert all(field in row for row in per), field
+    assert [row["matches_last_step"] for row in per] == [10 + r for r in range(8)]
+    assert per[7]["busy_s"] > 2 * per[0]["busy_s"]  # the rehearsal makes rank r slower with r: visible per rank ...
+    assert all(row["elapsed_s"] >= per[7]["busy_s"] * 0.99 for row in per)  # ... while every rank waited for the slowest
+    summ = out["config"]["per_rank_summary"]
+    assert summ["busy_s"][0] == per[0]["busy_s"] and summ["busy_s"][2] == per[7]["busy_s"]
+    assert summ["busy_s"][0] <= summ["busy_s"][1] <= summ["busy_s"][2] and "probe_tflops" not in summ  # no GPU here
 
 
 def test_export_predictions_sharded_world8_gloo_540_items(tmp_path):
