@@ -287,8 +287,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 
 // 2 x NW waves; every wave owns MT x MT MFMA tiles of 32x32.
 //   MT = 2, NW = 2, BK = 16: 128x128 tile, 256 threads, 40 KB LDS (4 workgroups / CU)    default for large problems
-//   MT = 2, NW = 4, BK = 32: 128x256 tile, 512 threads, 108 KB LDS (1 workgroup / CU)    knob only
-//   MT = 2, NW = 2, BK = 32: 128x128 tile, 256 threads,  72 KB LDS (2 workgroups / CU)   knob only
 //   MT = 1, NW = 2, BK = 32:  64x64  tile, 256 threads,  36 KB LDS (4 workgroups / CU)   small M (batch 1..4):
 //                    4x the workgroups, so that a [2048, 256] GEMM still covers the chip
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
@@ -896,121 +894,6 @@ extern "C" int gfc_linear_layernorm_gelu(const float* A0, int lda0, int K0, cons
   return launch_rows512<2>(g, gamma, beta, (hipStream_t)stream);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant (128x128 tile, 16-deep K tile, 4 waves): operands go global -> LDS with global_load_lds_dwordx4,
-// no staging registers and no ds_write.  One wave-instruction writes 1 KB = 16 unpadded rows of 16 floats, lane i
-// to byte 16*i; bank conflicts of the fragment reads are avoided by an XOR swizzle of the four 16-byte chunks of a
-// row with (row >> 2) & 3, applied to the SOURCE address of the DMA and to the fragment read address (the LDS
-// destination itself has to stay linear).  32 KB of K-loop LDS (34.8 KB with the epilogue patches) and ~100 VGPRs:
-// four workgroups per CU instead of three.
-// ---------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-__global__ __launch_bounds__(256, 4) void gemm_nt_dma_kernel(GemmArgs g) {
-  constexpr int NW = 2, MT = 2, BM = 128, BN = 128, BK = 16;
-  constexpr int TILE = (BM + BN) * BK;  // floats per buffer
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, h = lane >> 5;
-  const int wm = wave / NW, wn = wave % NW;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  const long long z = blockIdx.z;
-  const float* A0 = g.A0 + z * g.strideA;
-  const float* A1 = g.A1 ? g.A1 + z * g.strideA : nullptr;
-  const float* W = g.W + z * g.strideW;
-  float* Y = g.Y + z * g.strideY;
-  const int ktiles = (g.K0 + g.K1) / BK;
-
-  // this lane's share of the wave's four 1 KB pieces (A pieces 2w, 2w+1 and W pieces 2w, 2w+1 of a tile)
-  const int rl = lane >> 2, slot = lane & 3;
-  const int r0 = 32 * wave + rl, r1 = r0 + 16;                 // tile rows of the two pieces
-  const int c0 = 4 * (slot ^ ((r0 >> 2) & 3)), c1 = 4 * (slot ^ ((r1 >> 2) & 3));  // logical k offset of the chunk
-  const size_t ar0 = (size_t)min(m0 + r0, g.M - 1), ar1 = (size_t)min(m0 + r1, g.M - 1);
-  const float* w0p = W + (size_t)min(n0 + r0, g.N - 1) * g.ldw + c0;
-  const float* w1p = W + (size_t)min(n0 + r1, g.N - 1) * g.ldw + c1;
-  // Issued through inline assembly: with the builtin, hipcc drains vmcnt(0) in front of the next ds_read (it cannot
-  // prove that the fragment reads do not alias the DMA destination), which serialises load and compute.  Here the
-  // compiler does not see the outstanding DMA; the wait is placed by hand in front of the barrier that ends the step.
-#define GEMM_GLDS(gsrc_, ldst_)                                                                         \
-  do {                                                                                                  \
-    unsigned keep_;                                                                                     \
-    const unsigned la_ = (unsigned)(size_t)(lds_ptr_t)(ldst_);                                          \
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                 : "=&s"(keep_)                                                                         \
-                 : "v"(gsrc_), "s"(__builtin_amdgcn_readfirstlane(la_))                                 \
-                 : "memory");                                                                           \
-  } while (0)
-#define GEMM_DMA_TILE(kt, buf_)                                                                         \
-  do {                                                                                                  \
-    const int k0_ = (kt) * BK;                                                                          \
-    const bool first_ = k0_ < g.K0;                                                                     \
-    const float* ab_ = (first_ ? A0 : A1) + (first_ ? k0_ : k0_ - g.K0);                                \
-    const size_t ld_ = first_ ? g.lda0 : g.lda1;                                                        \
-    float* as_ = smem + (buf_) * TILE + 512 * wave; /* 2 pieces of 256 floats per wave */               \
-    float* bs_ = as_ + BM * BK;                                                                         \
-    GEMM_GLDS(ab_ + ar0 * ld_ + c0, as_);                                                               \
-    GEMM_GLDS(ab_ + ar1 * ld_ + c1, as_ + 256);                                                         \
-    GEMM_GLDS(w0p + k0_, bs_);                                                                          \
-    GEMM_GLDS(w1p + k0_, bs_ + 256);                                                                    \
-  } while (0)
-
-  f32x16 acc[MT][MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < MT; ++nt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-  // fragment rows wm*64 + mt*32 + l31: (row >> 2) & 3 == (l31 >> 2) & 3 for both operands
-  const int sw = (l31 >> 2) & 3;
-  const int a_row = (wm * 64 + l31) * BK, b_row = BM * BK + (wn * 64 + l31) * BK;
-  const int ch0 = 4 * ((0 + h) ^ sw), ch1 = 4 * ((2 + h) ^ sw);  // k group 0: chunk h, k group 1: chunk 2 + h
-
-  GEMM_DMA_TILE(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = 0; kt < ktiles; ++kt) {
-    if (kt + 1 < ktiles) GEMM_DMA_TILE(kt + 1, (kt + 1) & 1);
-    const float* ap = smem + (kt & 1) * TILE + a_row;
-    const float* bp = smem + (kt & 1) * TILE + b_row;
-#pragma unroll
-    for (int gk = 0; gk < 2; ++gk) {
-      const int ch = gk ? ch1 : ch0;
-      float4 af[MT], bf[MT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * BK + ch);
-        bf[mt] = *reinterpret_cast<const float4*>(bp + mt * 32 * BK + ch);
-      }
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < MT; ++nt) {
-          acc[mt][nt] = mfma32(af[mt].x, bf[nt].x, acc[mt][nt]);
-          acc[mt][nt] = mfma32(af[mt].y, bf[nt].y, acc[mt][nt]);
-          acc[mt][nt] = mfma32(af[mt].z, bf[nt].z, acc[mt][nt]);
-          acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of tile kt+1 has landed
-    __syncthreads();
-  }
-#undef GEMM_DMA_TILE
-#undef GEMM_GLDS
-  gemm_epilogue<NW, MT>(g, acc, smem, Y, m0, n0, wm, wn, lane, wave);
-}
-
-static int launch_gemm_dma(const GemmArgs& g, int batch, hipStream_t st) {
-  constexpr size_t kloop = (size_t)2 * 256 * 16, patches = (size_t)2 * 2 * 32 * (64 + 4);
-  const size_t lds = (kloop > patches ? kloop : patches) * sizeof(float);
-  dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, batch);
-  hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(256), lds, st, g);
-  GFC_LAUNCH_CHECK();
-  return GFC_OK;
-}
-
 template <int NW, int MT, int BK, int MTN = MT>
 static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   constexpr int BM = 64 * MT, BN = 32 * MTN * NW;
@@ -1035,25 +918,19 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
 }
 
 static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
-  // tuning knob (tools/bench_kernels.py): GFC_GEMM_TILE=1 (128x256) | 2 (128x128) | 3 (64x64) | 4 (128x128, K tile 16)
-  // | 5 (64x64, K tile 16)
+  // GFC_GEMM_TILE forces one of the two tiles for every problem size: 4 = 128x128 (K tile 16), 3 = 64x64 (K tile 32);
+  // 0 / unset / anything else = by problem size.  (The 128x256, 256x128, 64x32, 16-deep 64x64 and LDS-DMA variants of
+  // rounds 2-5 measured no faster anywhere and were removed in round 6: TUNING_LOG.md.)
   const int forced = gfc_knobs().gemm_tile;
   auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
-  int choice = forced;
+  int choice = (forced == 3 || forced == 4) ? forced : 0;
   if (!choice) {
     // 128x128 tiles with a 16-deep K tile (40 KB LDS, four workgroups per CU: while one drains its stores the
     // others keep the MFMA pipe busy; +5..11 % over the 32-deep variants at M = 65536) once there are three per CU,
     // else 64x64 tiles so that small-batch GEMMs still cover the chip
     choice = tiles(128, 128) >= 768 ? 4 : 3;
   }
-  if (choice == 1) return launch_gemm_t<4, 2, 32>(g, batch, st);
-  if (choice == 2) return launch_gemm_t<2, 2, 32>(g, batch, st);
   if (choice == 4) return launch_gemm_t<2, 2, 16>(g, batch, st);  // 40 KB LDS: 4 workgroups / CU
-  if (choice == 5) return launch_gemm_t<2, 1, 16>(g, batch, st);  // 64x64, 20 KB LDS
-  if (choice == 6) return launch_gemm_t<4, 2, 16>(g, batch, st);
-  if (choice == 9) return launch_gemm_t<1, 1, 32>(g, batch, st);  // 64x32, two waves (knob only: neutral at batch 1)
-  if (choice == 8) return launch_gemm_t<2, 4, 16, 2>(g, batch, st);  // 256x128: 8 accumulator tiles per wave, 2 workgroups / CU
-  if (choice == 7) return launch_gemm_dma(g, batch, st);          // 128x128, LDS-DMA staging, 4 workgroups / CU  // 128x256, 61 KB LDS: 2 workgroups of 8 waves / CU
   return launch_gemm_t<2, 1, 32>(g, batch, st);
 }
 

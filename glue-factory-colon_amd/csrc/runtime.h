@@ -12,7 +12,7 @@
 #include <atomic>
 
 struct GfcKnobs {
-  int gemm_tile;     // GFC_GEMM_TILE: 0 = automatic
+  int gemm_tile;     // GFC_GEMM_TILE: 0 = by problem size, 3 = 64x64 tiles everywhere, 4 = 128x128 tiles everywhere
   int attn_cfg;      // GFC_ATTN_CFG: 0 = automatic
   int conv_kc;       // GFC_CONV_KC: 0 = automatic
   int conv_persist;  // GFC_CONV_PERSIST: -1 = automatic

@@ -8,7 +8,9 @@
 // tiles), the dustbin channel as one fmaf chain per cell on the VALU, the logits tile in LDS, statistics and outputs
 // with the arithmetic of the softmax_d2s_kernel of rounds 1-4 (max, then the sum of expf(l - max) over c = 0..64 in order).
 //
-// Bit-identical to the two-launch form: the K loop feeds the MFMAs exactly like gemm_nt_kernel (lane half h supplies
+// Built to give the bits of the two-launch form, which was measured identical on the round-5 workloads when that form was
+// retired and no longer exists to compare with; the test (test_detector_head_fused_softmax_d2s) holds the kernel to
+// 1e-7 and equal per-cell arg-max against an fp32 restatement.  The construction: the K loop feeds the MFMAs exactly like gemm_nt_kernel (lane half h supplies
 // k = 8g + 4h + s in step s of k group g), v_mfma_f32_32x32x2_f32 accumulates its two products in k order with one
 // rounding each (the conv1a-on-the-matrix-pipe finding of round 3), so the dustbin's VALU chain
 // fmaf(a[8g+s], w[8g+s], .) then fmaf(a[8g+4+s], w[8g+4+s], .) reproduces the value the GEMM's third column tile
@@ -178,6 +180,8 @@ int gfc_det_head_softmax_d2s(const float* hidden, int lda, const float* wp, cons
                              const float* shift, int B, int h8, int w8, float* heat, hipStream_t st) {
   if (!hidden || !wp || !bias || !heat || B <= 0 || h8 <= 0 || w8 <= 0 || lda < DH_K || lda % 4) return GFC_ERR_INVALID;
   if ((scale == nullptr) != (shift == nullptr)) return GFC_ERR_INVALID;
+  // float4 loads of both operands: 16-byte aligned bases (lda % 4 keeps every row aligned)
+  if ((reinterpret_cast<size_t>(hidden) | reinterpret_cast<size_t>(wp)) & 15) return GFC_ERR_INVALID;
   const long long rows = (long long)B * h8 * w8;
   const long long grid = (rows + DH_ROWS - 1) / DH_ROWS;
   if (grid >= (1ll << 31)) return GFC_ERR_UNSUPPORTED;

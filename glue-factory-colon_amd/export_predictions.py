@@ -391,13 +391,34 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
     tasks: "queue.Queue" = queue.Queue(maxsize=2 * workers)
     results, errors = [], []
 
+    def device_tensors(obj):
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                yield obj
+        elif isinstance(obj, dict):
+            for v in obj.values():
+                yield from device_tensors(v)
+        elif isinstance(obj, (list, tuple)):
+            for v in obj:
+                yield from device_tensors(v)
+
     def run(replica, stream):
         with torch.no_grad(), torch.cuda.stream(stream):
             while True:
-                chunk = tasks.get()
-                if chunk is None:
+                task = tasks.get()
+                if task is None:
                     return
+                chunk, ready = task
                 try:
+                    if ready is not None:
+                        # the items arrived ON THE DEVICE (image_preprocessor.HostImageFeeder: H2D copy + resize kernel
+                        # queued on the producing thread's stream): order this stream after the producer, and tell the
+                        # caching allocator that this stream uses the tensors, so their memory is not recycled for the
+                        # producer's next item while a kernel here still reads it
+                        stream.wait_event(ready)
+                        for _, item in chunk:
+                            for t in device_tensors(item):
+                                t.record_stream(stream)
                     results.extend(run_chunk(replica, chunk))  # list.extend is atomic under the GIL
                 except Exception as e:  # noqa: BLE001 -- re-raised in the caller's thread
                     errors.append(e)
@@ -405,10 +426,14 @@ def _export_loop(indexed, model, device, keys, optional_keys, callback_fn, as_ha
     threads = [threading.Thread(target=run, args=(r, st), daemon=True) for r, st in zip(replicas, streams)]
     for t in threads:
         t.start()
-    for chunk in _batches(indexed, pair_batch):
+    for chunk in _batches(indexed, pair_batch):  # the loader is iterated HERE, on the caller's thread and stream
         if errors:
             break
-        tasks.put(chunk)
+        ready = None
+        if any(True for _, item in chunk for _ in device_tensors(item)):
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))  # after everything the loader queued for these items
+        tasks.put((chunk, ready))
     for _ in threads:
         tasks.put(None)
     for t in threads:

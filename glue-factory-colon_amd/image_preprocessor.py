@@ -130,14 +130,22 @@ class HostImageFeeder:
     behind the copy's event; `scales` / `image_size` / `original_image_size` (host arithmetic) follow in one small
     pinned copy per item.  No host synchronisation anywhere: the export loop's kernels and the next items' copies overlap.
     Yields batch-1 items (`image` [1,C,h,w] float32, `scales` [1,2], `image_size` [1,2], `original_image_size` [1,2],
-    `transform` [1,3,3] float64 on the host), i.e. what the reference's DataLoader collates."""
+    `transform` [1,3,3] float64 on the host) with the keys and shapes the reference's DataLoader collates.  One
+    difference, deliberate: the reference's `image_size` / `original_image_size` are integer arrays (image.py:52-58) that
+    collate to int64 HOST tensors; here they are float32 DEVICE tensors holding the same integers (slices of the item's one
+    small meta copy), which is what the extractor and matcher consume (lightglue.py:28-40 divides them) without a
+    second copy or a host synchronisation.  Code that writes them into records gets floats (tests/test_preprocess.py).
+
+    raw_items may be any iterable; `len()` and `shard()` index it when it is a sequence, otherwise `shard()` walks it
+    and skips the other ranks' items (nothing of theirs is copied), and `len()` raises TypeError as the iterable's
+    would.  Every iteration keeps its own ring and name table: two live iterators over one feeder do not interact."""
 
     def __init__(self, raw_items, conf, device="cuda", depth=64, bgr=False, view_key=None, keep=16):
         """view_key (optional): `view_key(raw_item, i) -> hashable or None`, the NAME of the image of view i; a name seen among
         the last `keep` named images is neither copied nor resized again -- the item gets the tensors of its first occurrence
         (an HPatches sequence names its image 1 as view 0 of all five of its pairs, datasets/hpatches.py:98-99)."""
         self.raw, self.pre, self.depth, self.bgr = raw_items, ImagePreprocessor(conf), max(1, int(depth)), bool(bgr)
-        self.view_key, self.keep, self._named = view_key, max(1, int(keep)), {}
+        self.view_key, self.keep = view_key, max(1, int(keep))
         if self.pre.conf["square_pad"]:
             raise NotImplementedError("square_pad on the host-image path")
         if self.pre.conf["interpolation"] != "bilinear":
@@ -148,13 +156,15 @@ class HostImageFeeder:
     def __len__(self):
         return len(self.raw)
 
-    def _stage(self, raw, copy_stream, slot):
-        """Issue the copies of one item on the copy stream; returns what `_finish` needs."""
+    def _stage(self, raw, copy_stream, slot, state):
+        """Issue the copies of one item on the copy stream; returns what `_finish` needs.  state: this iteration's
+        (name table, (pinned meta ring, its events))."""
+        named, meta_ring = state
         views, meta, srcs = {}, [], []
         for i, tag in enumerate(("view0", "view1")):
             key = self.view_key(raw, i) if self.view_key is not None else None
-            if key is not None and key in self._named:
-                views[tag] = self._named[key]  # the first occurrence's record: filled by ITS _finish, which runs before ours
+            if key is not None and key in named:
+                views[tag] = named[key]  # the first occurrence's record: filled by ITS _finish, which runs before ours
                 meta += [0.0] * 6
                 continue
             u8 = raw[tag]["image"]
@@ -168,7 +178,7 @@ class HostImageFeeder:
             self.h2d_bytes += u8.numel()
         # the item's 12 numbers go through a slot of a pinned ring (allocated once); a slot comes round again after
         # `depth` + 1 items, when its copy has long completed (checked: the event is synchronised, which returns at once)
-        ring, events = self._meta_ring
+        ring, events = meta_ring
         if events[slot] is not None:
             events[slot].synchronize()
         ring[slot] = torch.tensor(meta, dtype=torch.float32)
@@ -177,9 +187,9 @@ class HostImageFeeder:
                 rec = {"dev": u8.to(self.device, non_blocking=True), "size": size, "hw": hw, "out": None}
                 views[tag] = rec
                 if key is not None:
-                    self._named[key] = rec
-                    while len(self._named) > self.keep:
-                        self._named.pop(next(iter(self._named)))  # oldest name first (insertion order)
+                    named[key] = rec
+                    while len(named) > self.keep:
+                        named.pop(next(iter(named)))  # oldest name first (insertion order)
             dev_meta = ring[slot].to(self.device, non_blocking=True)
             done = torch.cuda.Event()
             done.record(copy_stream)
@@ -220,14 +230,29 @@ class HostImageFeeder:
         """(index, item) of this rank's round-robin share (export_predictions' sharded mode, sharding.round_robin_shard:
         `group` consecutive items at a time): only this rank's images are copied and resized."""
         from .sharding import round_robin_shard
-        idx = round_robin_shard(len(self.raw), int(rank), int(world), int(group))
-        return zip(idx, self._iterate(self.raw[i] for i in idx))
+        rank, world, group = int(rank), int(world), max(1, int(group))
+        if hasattr(self.raw, "__getitem__") and hasattr(self.raw, "__len__"):
+            idx = round_robin_shard(len(self.raw), rank, world, group)
+            return zip(idx, self._iterate(self.raw[i] for i in idx))
+        # any other iterable (e.g. a DataLoader with batch_size=None): walk it, stage only this rank's items
+        mine_idx, mine = [], []
+
+        def own():
+            for i, raw in enumerate(self.raw):
+                if (i // group) % world == rank:
+                    mine_idx.append(i)
+                    yield raw
+
+        def pairs():
+            for n, item in enumerate(self._iterate(own())):
+                yield mine_idx[n], item
+
+        return pairs()
 
     def _iterate(self, raw_iterable):
-        self._named = {}
         copy_stream = torch.cuda.Stream(self.device)
         ring = self.depth + 1
-        self._meta_ring = (torch.empty((ring, 12), dtype=torch.float32).pin_memory(), [None] * ring)
+        state = ({}, (torch.empty((ring, 12), dtype=torch.float32).pin_memory(), [None] * ring))
         pending = deque()
         it = iter(raw_iterable)
         exhausted = False
@@ -235,7 +260,7 @@ class HostImageFeeder:
         while True:
             while not exhausted and len(pending) < self.depth:
                 try:
-                    pending.append(self._stage(next(it), copy_stream, n_staged % ring))
+                    pending.append(self._stage(next(it), copy_stream, n_staged % ring, state))
                     n_staged += 1
                 except StopIteration:
                     exhausted = True

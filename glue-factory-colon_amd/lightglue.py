@@ -230,12 +230,16 @@ class LightGlue(nn.Module):
                     run()
             e["graph"] = graph
         except (nat.NativeError, RuntimeError) as exc:
-            # the capture was refused (another thread is using the device) or a launch failed UNDER capture: the same
-            # launch sequence once more outside any capture -- an error status there is a real failure and propagates
-            run()
-            if not getattr(LightGlue, "_graph_fallback_logged", False):
-                LightGlue._graph_fallback_logged = True
-                print(f"glue_factory_colon_amd.lightglue: HIP graph capture failed ({exc}); problems of shape "
+            # RuntimeError: the capture was refused (another thread is using the device).  NativeError: raised by run()
+            # inside the `with` block, i.e. always while this stream was capturing -- the eager run above has just
+            # proved the same launch sequence on the same buffers, so the failure is specific to capture.  Either way
+            # this shape runs with eager launches from now on (the caller does that run: nothing is repeated here), and
+            # the reason is logged once per kind, never hidden.
+            kind = "launch failed under capture" if isinstance(exc, nat.NativeError) else "capture refused"
+            logged = LightGlue.__dict__.get("_graph_fallback_logged") or set()
+            if kind not in logged:
+                LightGlue._graph_fallback_logged = logged | {kind}
+                print(f"glue_factory_colon_amd.lightglue: HIP graph {kind} ({exc}); problems of shape "
                       f"{key[:3]} run with eager launches", file=sys.stderr)
             e = {"graph": None}
         self._graphs[key] = e

@@ -12,9 +12,15 @@
  *   - all pointers are DEVICE pointers (hipMalloc'ed or torch-allocated) unless marked
  *     "host"; fp32 everywhere, int32 for counts/tables, int64 for match indices
  *     (the reference returns torch.long, lightglue.py:294-319);
- *   - no allocation, no global state, no synchronisation inside: the caller passes a
- *     workspace of at least gfc_*_workspace_bytes() and a hipStream_t (as void*);
- *     every kernel is enqueued on that stream and the call returns immediately;
+ *   - no allocation and no synchronisation inside: the caller passes a workspace of at
+ *     least gfc_*_workspace_bytes() and a hipStream_t (as void*); every kernel is
+ *     enqueued on that stream and the call returns immediately;
+ *   - no MUTABLE global state: calls are re-entrant per stream and from any host thread.
+ *     What the library keeps process-wide is read-only after its first use and never
+ *     changes a result: the tuning knobs (GFC_GEMM_TILE, GFC_ATTN_CFG, ... read ONCE from
+ *     the environment by the first call, csrc/runtime.h -- set them before that call;
+ *     they select between kernel variants held to the same parity tests) and per-device
+ *     facts (CU count, the dynamic-LDS attribute of each kernel instantiation);
  *   - return value: 0 = ok, otherwise a gfc_status.  Nothing is written on error.
  *   - activations inside the extractor are NHWC ("channels last").
  */
@@ -223,6 +229,7 @@ int gfc_sp_dense(const gfc_sp_params* p, const float* image, int B, int C, int H
 /* Detector head in one launch: 1x1 convolution 256 -> 65 (+ eval-BN affine when scale / shift are given), softmax over the
  * 65 logits of every cell, dustbin dropped, 8x8 depth-to-space:  heat[b, 8y+i, 8x+j] = softmax_c(W . hidden[b,y,x,:] + b)[8i+j].
  * hidden [B*h8*w8][lda] NHWC rows (the detector's 256 hidden channels first, lda >= 256, a multiple of 4); w [65][256];
+ * hidden and w 16-byte aligned (GFC_ERR_INVALID otherwise: both are read with 128-bit loads);
  * bias / scale / shift [65] (scale and shift nullable together); heat [B][8 h8][8 w8].  The logits never reach HBM.
  * superpoint_open.py:111-114,138-144; superpoint.py:193-194,229-235 (part of gfc_sp_dense). */
 int gfc_sp_detector_head(const float* hidden, int lda, const float* w, const float* bias, const float* scale,

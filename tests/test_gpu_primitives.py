@@ -345,14 +345,14 @@ def test_linear_plain(m, n, k):
 
 
 def test_gemm_tile_variants_via_knob():
-    """Every GEMM variant behind GFC_GEMM_TILE (128x256, 128x128, 64x64 with 32/16-deep K tiles, the LDS-DMA kernel,
-    9 = the 64x32 two-wave tile small [M, 256] problems get by default)
-    passes the linear / batched tests; the knob is read once per process, hence child processes."""
+    """Both GEMM tiles of the library (GFC_GEMM_TILE = 4: 128x128 with a 16-deep K tile, 3: 64x64 with a 32-deep one),
+    each forced for EVERY problem size, pass the linear / batched tests (by default the size decides); the knob is read
+    once per process, hence child processes.  The other variants of rounds 2-5 were removed in round 6."""
     import subprocess
     import sys
 
     # 4 = gemm_nt_kernel<2,2,16>, the variant large batches (bench.py: 32 pairs) dispatch to by default
-    for tile in (1, 2, 3, 4, 5, 6, 7, 8, 9):
+    for tile in (3, 4):
         env = dict(os.environ, GFC_GEMM_TILE=str(tile))
         r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x",
                             "-k", "(linear_plain or linear_concat or linear_rotary or batched_nt) and not via_knob", "-p", "no:cacheprovider"],

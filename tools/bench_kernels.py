@@ -147,7 +147,7 @@ def bench_gemm_msweep():
 
 
 def bench_gemm_small():
-    """Batch-1 shapes (M = 2048 rows): tile choice 1 = 128x256, 2 = 128x128, 3 = 64x64 (GFC_GEMM_TILE)."""
+    """Batch-1 shapes (M = 2048 rows): GFC_GEMM_TILE 3 = 64x64 tiles, 4 = 128x128 tiles, unset = by problem size."""
     lib = nat.lib()
     st = nat.stream_ptr(DEV)
     for m in (2048, 8192):
