@@ -1,0 +1,169 @@
+"""HPatches sequences read from a directory, feeding the GPU path -- counterpart of `gluefactory.datasets.hpatches`
+(reference gluefactory/datasets/hpatches.py:23-35 `read_homography`, :38-77 sequence list, :94-112 items) and of the
+file decode it relies on (gluefactory/utils/image.py:135-161: `cv2.imread` -> RGB uint8 -> float / 255).
+
+HPatches ships binary PPM files (`<seq>/1.ppm` .. `6.ppm`) and plain-text 3x3 homographies (`<seq>/H_1_<q>`).  A binary
+PPM / PGM is a short text header followed by the raw samples, so reading it needs no image library and is exact by
+construction: the bytes of the file ARE the decoded image (cv2 / PIL are absent in this image).  `HPatches` lists the
+pairs exactly as the reference's dataset does and yields RAW items -- decoded uint8 images in (pinned) host memory plus
+`H_0to1`, `scene`, `idx`, `is_illu`, `name` -- for `image_preprocessor.HostImageFeeder`, which copies them to the GPU and
+does the reference's ImagePreprocessor work there.  No download: the reference fetches the archive when the directory
+is missing (hpatches.py:57,79-88); here a missing directory is an error.
+
+Not pinned against cv2 (absent): the GREY decode of a COLOUR file (`grayscale=True`, not the evaluation's default,
+hpatches.py:43) uses the 14-bit fixed-point weights OpenCV documents for BGR->GRAY; 16-bit files are refused.
+"""
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from .base_model import merge
+from .image_preprocessor import DEFAULT_CONF as PREPROCESSING_DEFAULTS
+from .image_preprocessor import HostImageFeeder, ImagePreprocessor
+
+
+def _header_tokens(buf: bytes, count: int):
+    """The first `count` whitespace-separated header tokens of a netpbm file ('#' starts a comment that runs to the end
+    of the line) and the offset of the byte after the single whitespace that ends the last one."""
+    tokens, pos, n = [], 0, len(buf)
+    while len(tokens) < count:
+        while pos < n and (buf[pos:pos + 1].isspace() or buf[pos:pos + 1] == b"#"):
+            if buf[pos:pos + 1] == b"#":
+                while pos < n and buf[pos:pos + 1] not in (b"\n", b"\r"):
+                    pos += 1
+            else:
+                pos += 1
+        start = pos
+        while pos < n and not buf[pos:pos + 1].isspace() and buf[pos:pos + 1] != b"#":
+            pos += 1
+        if start == pos:
+            raise IOError("truncated netpbm header")
+        tokens.append(buf[start:pos])
+    return tokens, pos + 1  # exactly one whitespace byte separates the header from the raster
+
+
+def read_ppm(path, grayscale: bool = False) -> np.ndarray:
+    """Binary (P6 / P5) or plain (P3 / P2) PPM / PGM file -> uint8 array, [H,W,3] RGB or, with `grayscale`, [H,W] --
+    what `read_image` returns (gluefactory/utils/image.py:135-146: cv2.imread + BGR->RGB flip, or IMREAD_GRAYSCALE).
+    A grey file read as colour has its channel repeated three times, as cv2.IMREAD_COLOR does."""
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(f"No image at path {path}.")
+    buf = path.read_bytes()
+    magic = buf[:2]
+    if magic not in (b"P6", b"P5", b"P3", b"P2"):
+        raise IOError(f"Could not read image at {path}.")  # the reference's error for a file cv2 cannot decode
+    (_, w, h, maxval), off = _header_tokens(buf, 4)
+    w, h, maxval = int(w), int(h), int(maxval)
+    if maxval != 255:
+        raise NotImplementedError(f"{path}: maxval {maxval}; only 8-bit files (maxval 255) are read")
+    c = 3 if magic in (b"P6", b"P3") else 1
+    if magic in (b"P6", b"P5"):
+        if len(buf) - off < h * w * c:
+            raise IOError(f"Could not read image at {path}.")
+        img = np.frombuffer(buf, np.uint8, h * w * c, off).reshape(h, w, c)
+    else:
+        vals = np.array(buf[off - 1:].split()[: h * w * c], dtype=np.int64)
+        if vals.size != h * w * c:
+            raise IOError(f"Could not read image at {path}.")
+        img = vals.astype(np.uint8).reshape(h, w, c)
+    if grayscale:
+        if c == 1:
+            return np.ascontiguousarray(img[..., 0])
+        r, g, b = (img[..., i].astype(np.int32) for i in range(3))
+        return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)  # OpenCV's 14-bit BGR2GRAY weights
+    return np.repeat(img, 3, axis=2) if c == 1 else img.copy()  # a writable array of its own (frombuffer views the file buffer)
+
+
+def read_homography(path) -> np.ndarray:
+    """Whitespace-separated 3x3 text matrix -> float64 array (hpatches.py:23-35: runs of spaces, trailing spaces and
+    empty lines are tolerated)."""
+    rows = []
+    with open(path) as f:
+        for line in f.readlines():
+            elements = [e for e in line.replace("\n", "").split(" ") if e]
+            if elements:
+                rows.append(elements)
+    return np.array(rows).astype(float)
+
+
+class HPatches:
+    """The reference dataset's pair list over a local `hpatches-sequences-release` directory, as a SEQUENCE of raw
+    loader items (`len()`, indexing, iteration): item i = pair (`<seq>/1.ppm`, `<seq>/<q>.ppm`), q = 2..6."""
+
+    default_conf = {
+        "preprocessing": PREPROCESSING_DEFAULTS,
+        "data_dir": "hpatches-sequences-release",  # absolute, or relative to $GFC_DATA_PATH / the current directory
+        "subset": None,              # "i" (illumination) or "v" (viewpoint) sequences only
+        "ignore_large_images": True,
+        "grayscale": False,
+        "pin_memory": True,          # decoded images in pinned host memory: their copies to the GPU are asynchronous
+    }
+    # hpatches.py:46-56 (spelling as in the reference: these are directory names)
+    ignored_scenes = ("i_contruction", "i_crownnight", "i_dc", "i_pencils", "i_whitebuilding", "v_artisans",
+                      "v_astronautis", "v_talent")
+
+    def __init__(self, conf=None):
+        self.conf = conf = merge(self.default_conf, dict(conf or {}))
+        self.preprocessor = ImagePreprocessor(conf["preprocessing"])
+        root = Path(conf["data_dir"])
+        if not root.is_absolute():
+            root = Path(os.environ.get("GFC_DATA_PATH", ".")) / root
+        if not root.is_dir():
+            raise FileNotFoundError(f"HPatches directory {root} not found (no download is attempted: the dataset must "
+                                    "be on the machine)")
+        self.root = root
+        self.sequences = sorted(x.name for x in root.iterdir())
+        if not self.sequences:
+            raise ValueError("No image found!")
+        self.items = []  # (seq, q_idx, is_illu)
+        for seq in self.sequences:
+            if conf["ignore_large_images"] and seq in self.ignored_scenes:
+                continue
+            if conf["subset"] is not None and conf["subset"] != seq[0]:
+                continue
+            for i in range(2, 7):
+                self.items.append((seq, i, seq[0] == "i"))
+
+    def __len__(self):
+        return len(self.items)
+
+    def _transform(self, h, w):
+        """`T` of ImagePreprocessor.__call__ (image.py:49-50): diag of the fp32-rounded resize scales, as float64."""
+        size = (h, w) if self.preprocessor.conf["resize"] is None else tuple(self.preprocessor.get_new_image_size(h, w))
+        return np.diag([np.float32(size[1] / w), np.float32(size[0] / h), 1.0]).astype(np.float64)
+
+    def _read(self, seq, idx):
+        img = torch.from_numpy(read_ppm(self.root / seq / f"{idx}.ppm", self.conf["grayscale"]))
+        if self.conf["pin_memory"] and torch.cuda.is_available():
+            img = img.pin_memory()
+        return img
+
+    def __getitem__(self, idx):
+        """Raw item of pair `idx` (hpatches.py:98-112), already in the collated shapes a batch-1 DataLoader gives:
+        `H_0to1` [1,3,3] float32 in the coordinates of the PREPROCESSED images (T1 . H . T0^-1), `idx` [1], `is_illu` [1],
+        `scene` / `name` strings (the feeder wraps them in lists), view images as decoded uint8 [H,W,3] (or [H,W])."""
+        seq, q_idx, is_illu = self.items[idx]
+        img0, img1 = self._read(seq, 1), self._read(seq, q_idx)
+        H = read_homography(self.root / seq / f"H_1_{q_idx}")
+        H = self._transform(*img1.shape[:2]) @ H @ np.linalg.inv(self._transform(*img0.shape[:2]))
+        return {"H_0to1": torch.from_numpy(H.astype(np.float32))[None], "scene": seq, "idx": torch.tensor([idx]),
+                "is_illu": torch.tensor([is_illu]), "name": f"{seq}/{idx}.ppm", "view0": {"image": img0},
+                "view1": {"image": img1}}
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def feeder(self, device="cuda", depth=16, keep=4):
+        """The loader for `export_predictions`: items preprocessed on the GPU; the sequence's image 1 -- view 0 of all
+        five of its pairs -- is copied and resized once (`view_key`, also what `export_predictions(view_key=...)` takes
+        to extract it once)."""
+        return HostImageFeeder(self, self.conf["preprocessing"], device=device, depth=depth, view_key=self.view_key,
+                               keep=keep)
+
+    @staticmethod
+    def view_key(raw, i):
+        scene = raw["scene"][0] if isinstance(raw["scene"], (list, tuple)) else raw["scene"]
+        return (scene, 1) if i == 0 else None

@@ -44,3 +44,10 @@ def test_bench_line_contract():
     assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["cores"] >= 1
     assert d["self_check"]["pairs_equal"] is True and d["self_check"]["keypoint_sets_equal"] is True
     assert not any(k in d for k in ("batch1", "c3_regime", "c4", "config5"))  # skipped by --no-batch1
+    # every rank's own numbers ride on the line (one row at N = 1): the N > 1 line explains itself
+    per = d["config"]["per_rank"]
+    assert len(per) == 1 and per[0]["rank"] == 0 and d["config"]["rccl_ranks"] == 1
+    assert 0 < per[0]["busy_s"] <= per[0]["elapsed_s"] and abs(per[0]["elapsed_s"] - d["ms_per_step"] * 3e-3) < 1e-3
+    assert abs(per[0]["attention_avg_launch_ms"] - roof["avg_launch_ms"]) < 1e-3 and per[0]["stem_avg_launch_ms"] > 0
+    assert per[0]["probe_tflops"] == roof["sustained_mfma_probe"]["tflops"] and 1.0 < per[0]["probe_shader_clock_ghz"] < 2.6
+    assert d["config"]["per_rank_summary"]["busy_s"] == [per[0]["busy_s"]] * 3

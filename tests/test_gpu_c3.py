@@ -282,6 +282,13 @@ def test_export_from_host_uint8_images_with_gpu_preprocessing(tmp_path):
     one = load_predictions(export_predictions(list(HostImageFeeder(raw, conf)), official_pipeline(),
                                               tmp_path / "one.npz", keys=keys))
     _assert_records_equal(one, bat, 40)
+    # the feeder consumed LIVE (not materialised into a list) by export workers on their own HIP streams: the items'
+    # copies and resize kernels are queued on the caller's stream as the loader is iterated, the extractor runs on a
+    # worker's stream -- ordered by an event per chunk and `record_stream` (export_predictions._export_loop); a small
+    # `depth` makes the feeder recycle its device buffers while the workers are still reading earlier ones
+    wk = load_predictions(export_predictions(HostImageFeeder(raw, conf, depth=2), official_pipeline(), tmp_path / "wk.npz",
+                                             keys=keys, workers=2))
+    _assert_records_equal(wk, bat, 40)
     # a float image is not a decoded image
     bad = [dict(raw[0]), {**raw[1], "view1": {"image": raw[1]["view1"]["image"].float()}}]
     with pytest.raises(ValueError, match="expected a decoded uint8 image"):

@@ -1,0 +1,170 @@
+"""The dependency-free reader of the files HPatches ships (glue_factory_colon_amd/hpatches.py): binary PPM / PGM decode,
+`read_homography`, the pair list -- reference gluefactory/datasets/hpatches.py:23-35,38-77,94-112 and
+gluefactory/utils/image.py:135-161.  A binary PPM is raw bytes behind a text header, so the files are written by the test
+itself and the decode must return exactly those bytes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from glue_factory_colon_amd import hpatches
+
+
+def write_ppm(path, img, comment=False):
+    h, w = img.shape[:2]
+    magic = b"P6" if img.ndim == 3 else b"P5"
+    head = magic + b"\n" + (b"# made by a test\n" if comment else b"") + f"{w} {h}\n255\n".encode()
+    with open(path, "wb") as f:
+        f.write(head + img.tobytes())
+
+
+def make_tree(root, seqs, rng, size=(48, 64)):
+    """<root>/<seq>/{1..6}.ppm and H_1_{2..6}; returns {seq: ([images], [H])}."""
+    out = {}
+    for s, seq in enumerate(seqs):
+        d = root / seq
+        d.mkdir(parents=True)
+        imgs, hs = [], []
+        for i in range(1, 7):
+            h, w = size[0] + 2 * ((s + i) % 3), size[1] + 4 * (i % 2)
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            write_ppm(d / f"{i}.ppm", img, comment=i == 2)
+            imgs.append(img)
+        for q in range(2, 7):
+            H = np.eye(3) + rng.normal(0, 0.01, (3, 3))
+            H[2, 2] = 1.0
+            hs.append(H)
+            rows = ["   ".join(f"{v:.8g}" for v in row) + " " for row in H]  # runs of spaces, trailing space
+            (d / f"H_1_{q}").write_text("\n".join(rows) + "\n\n")
+        out[seq] = (imgs, hs)
+    return out
+
+
+def test_read_ppm_returns_the_bytes_of_the_file(tmp_path):
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    grey = rng.integers(0, 256, (21, 34), dtype=np.uint8)
+    write_ppm(tmp_path / "a.ppm", rgb, comment=True)
+    write_ppm(tmp_path / "b.pgm", grey)
+    a = hpatches.read_ppm(tmp_path / "a.ppm")
+    assert a.dtype == np.uint8 and a.shape == (37, 53, 3) and np.array_equal(a, rgb)
+    assert np.array_equal(hpatches.read_ppm(tmp_path / "b.pgm", grayscale=True), grey)
+    b3 = hpatches.read_ppm(tmp_path / "b.pgm")  # a grey file read as colour: the channel three times
+    assert b3.shape == (21, 34, 3) and all(np.array_equal(b3[..., c], grey) for c in range(3))
+    g = hpatches.read_ppm(tmp_path / "a.ppm", grayscale=True)  # colour file read as grey: 0.299 R + 0.587 G + 0.114 B
+    exact = rgb.astype(np.float64) @ np.array([0.299, 0.587, 0.114])
+    assert g.shape == (37, 53) and np.abs(g.astype(np.float64) - exact).max() <= 0.51
+    # the value 10 (a newline byte) as the first sample: exactly ONE whitespace byte ends the header
+    tricky = np.full((2, 2, 3), 10, np.uint8)
+    write_ppm(tmp_path / "t.ppm", tricky)
+    assert np.array_equal(hpatches.read_ppm(tmp_path / "t.ppm"), tricky)
+    # plain (ASCII) variant
+    (tmp_path / "p.ppm").write_text("P3\n# c\n2 1\n255\n1 2 3\n250 251 252\n")
+    assert hpatches.read_ppm(tmp_path / "p.ppm").tolist() == [[[1, 2, 3], [250, 251, 252]]]
+    # the reference's errors (image.py:137-143)
+    with pytest.raises(FileNotFoundError, match="No image at path"):
+        hpatches.read_ppm(tmp_path / "missing.ppm")
+    (tmp_path / "bad.ppm").write_bytes(b"\x89PNG....")
+    with pytest.raises(IOError, match="Could not read image"):
+        hpatches.read_ppm(tmp_path / "bad.ppm")
+    (tmp_path / "short.ppm").write_bytes(b"P6\n4 4\n255\n" + bytes(10))
+    with pytest.raises(IOError, match="Could not read image"):
+        hpatches.read_ppm(tmp_path / "short.ppm")
+    (tmp_path / "deep.ppm").write_bytes(b"P6\n1 1\n65535\n" + bytes(6))
+    with pytest.raises(NotImplementedError):
+        hpatches.read_ppm(tmp_path / "deep.ppm")
+
+
+def test_read_homography_tolerates_the_formats_hpatches_uses(tmp_path):
+    p = tmp_path / "H_1_2"
+    p.write_text("0.87977   0.31245  -39.431 \n-0.18389  0.93847   153.16\n\n0.00019641 -1.6015e-05  1\n")
+    H = hpatches.read_homography(p)
+    assert H.dtype == np.float64 and H.shape == (3, 3)
+    assert H.tolist() == [[0.87977, 0.31245, -39.431], [-0.18389, 0.93847, 153.16], [0.00019641, -1.6015e-05, 1.0]]
+
+
+def test_pair_list_and_raw_items(tmp_path):
+    rng = np.random.default_rng(1)
+    seqs = ["i_ajuntament", "v_bark", "v_talent", "i_dc", "v_zzz"]
+    tree = make_tree(tmp_path / "hp", seqs, rng)
+    ds = hpatches.HPatches({"data_dir": str(tmp_path / "hp"), "preprocessing": {"resize": 32, "side": "short"},
+                            "pin_memory": False})
+    # sorted sequences, the large scenes of earlier papers dropped (hpatches.py:46-56,68-69), five pairs each
+    assert ds.sequences == sorted(seqs) and len(ds) == 15
+    assert [it[:2] for it in ds.items[:6]] == [("i_ajuntament", q) for q in range(2, 7)] + [("v_bark", 2)]
+    assert len(hpatches.HPatches({"data_dir": str(tmp_path / "hp"), "ignore_large_images": False})) == 25
+    assert {s for s, _, _ in hpatches.HPatches({"data_dir": str(tmp_path / "hp"), "subset": "v"}).items} == {"v_bark", "v_zzz"}
+    it = ds[6]  # v_bark, q = 3
+    imgs, hs = tree["v_bark"]
+    assert it["name"] == "v_bark/6.ppm" and it["scene"] == "v_bark" and it["idx"].tolist() == [6]  # name as hpatches.py:108
+    assert it["is_illu"].tolist() == [False] and ds[0]["is_illu"].tolist() == [True]
+    assert torch.equal(it["view0"]["image"], torch.from_numpy(imgs[0])) and it["view0"]["image"].dtype == torch.uint8
+    assert torch.equal(it["view1"]["image"], torch.from_numpy(imgs[2]))
+    # H_0to1 = T1 . H . T0^-1 with T = diag(fp32(new_w / w), fp32(new_h / h), 1) (hpatches.py:102-103, image.py:49-50)
+    pp = ds.preprocessor
+
+    def T(img):
+        h, w = img.shape[:2]
+        nh, nw = pp.get_new_image_size(h, w)
+        return np.diag([float(np.float32(nw / w)), float(np.float32(nh / h)), 1.0])
+
+    Hfile = hpatches.read_homography(tmp_path / "hp" / "v_bark" / "H_1_3")
+    assert np.abs(Hfile - hs[1]).max() < 1e-7
+    want = (T(imgs[2]) @ Hfile @ np.linalg.inv(T(imgs[0]))).astype(np.float32)
+    assert it["H_0to1"].shape == (1, 3, 3) and it["H_0to1"].dtype == torch.float32
+    assert np.array_equal(it["H_0to1"][0].numpy(), want)
+    assert len(list(iter(ds))) == 15
+    assert hpatches.HPatches.view_key(it, 0) == ("v_bark", 1) and hpatches.HPatches.view_key(it, 1) is None
+    assert hpatches.HPatches.view_key({"scene": ["v_bark"]}, 0) == ("v_bark", 1)  # collated form
+    with pytest.raises(FileNotFoundError, match="no download"):
+        hpatches.HPatches({"data_dir": str(tmp_path / "absent")})
+    os.environ["GFC_DATA_PATH"] = str(tmp_path)
+    try:
+        assert len(hpatches.HPatches({"data_dir": "hp"})) == 15  # relative to $GFC_DATA_PATH
+    finally:
+        del os.environ["GFC_DATA_PATH"]
+
+
+@pytest.mark.gpu
+def test_export_from_an_hpatches_directory(tmp_path):
+    """BASELINE config 3 from files: directory -> read_ppm -> HostImageFeeder -> export_predictions(pair_batch, view_key)
+    -> records named like the reference's, identical to the records of the same decoded images handed over directly."""
+    from glue_factory_colon_amd import synthetic
+    from glue_factory_colon_amd.export_predictions import export_predictions, load_predictions
+    from glue_factory_colon_amd.image_preprocessor import HostImageFeeder
+    from glue_factory_colon_amd.two_view_pipeline import TwoViewPipeline
+
+    raw = synthetic.hpatches_like_host_images(10, seed=5100, pin=False, shared_view0=True)  # two sequences of five pairs
+    root = tmp_path / "hpatches-sequences-release"
+    for i, it in enumerate(raw):
+        seq = "v_" + it["scene"]
+        (root / seq).mkdir(parents=True, exist_ok=True)
+        if i % 5 == 0:
+            write_ppm(root / seq / "1.ppm", it["view0"]["image"].numpy())
+        write_ppm(root / seq / f"{i % 5 + 2}.ppm", it["view1"]["image"].numpy())
+        (root / seq / f"H_1_{i % 5 + 2}").write_text("1 0 24\n0 1 16\n0 0 1\n")
+    conf = {"resize": 480, "side": "short"}
+    ds = hpatches.HPatches({"data_dir": str(root), "preprocessing": conf})
+    assert len(ds) == 10
+
+    def pipeline():
+        return TwoViewPipeline({
+            "extractor": {"name": "extractors.superpoint_open", "weights": "synthetic", "max_num_keypoints": 512,
+                          "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "matchers.lightglue", "weights": "synthetic", "filter_threshold": 0.1}}).eval().cuda()
+
+    keys = ["keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1"]
+    feeder = ds.feeder()
+    from_files = load_predictions(export_predictions(feeder, pipeline(), tmp_path / "files.npz", keys=keys, pair_batch=8,
+                                                     view_key=ds.view_key))
+    assert sorted(from_files) == sorted(f"v_{it['scene']}/{i}.ppm" for i, it in enumerate(raw))
+    # each sequence's image 1 travelled and was resized once
+    assert feeder.h2d_bytes == sum(it["view1"]["image"].numel() for it in raw) + sum(raw[i]["view0"]["image"].numel() for i in (0, 5))
+    direct_items = [{**it, "name": f"v_{it['scene']}/{i}.ppm"} for i, it in enumerate(raw)]
+    direct = load_predictions(export_predictions(HostImageFeeder(direct_items, conf), pipeline(), tmp_path / "direct.npz",
+                                                 keys=keys, pair_batch=8))
+    for name, rec in direct.items():
+        for k in keys:
+            assert np.array_equal(rec[k], from_files[name][k]), (name, k)
+    assert sum(int((r["matches0"] >= 0).sum()) for r in from_files.values()) > 10 * 50

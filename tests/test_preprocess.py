@@ -135,6 +135,27 @@ def test_host_image_feeder_items_and_round_robin_shard():
     assert [i for i, _ in share] == [1, 4]
     for i, it in share:
         assert torch.equal(it["view0"]["image"], items[i]["view0"]["image"]) and it["name"] == items[i]["name"]
+    # the reference's image_size / original_image_size are integer HOST tensors after collation; here: the same integers
+    # as float32 DEVICE tensors (documented difference, HostImageFeeder docstring)
+    d = items[0]["view0"]
+    assert d["image_size"].dtype == torch.float32 and d["image_size"].is_cuda and d["image_size"].shape == (1, 2)
+    assert torch.equal(d["image_size"], d["image_size"].round()) and torch.equal(d["original_image_size"][0].cpu(),
+                                                                                 torch.tensor([120.0, 90.0]))
+    # raw items from a plain iterable (no len(), no indexing: e.g. a DataLoader with batch_size=None): shard() walks it and
+    # stages only this rank's items; grouped round-robin; two live iterators over ONE feeder do not disturb each other
+    lazy = HostImageFeeder((r for r in raw), conf, depth=2)
+    with pytest.raises(TypeError):
+        len(lazy)
+    share = list(lazy.shard(1, 2, group=2))
+    assert [i for i, _ in share] == [2, 3, 6] and lazy.h2d_bytes == sum(raw[i][v]["image"].numel() for i in (2, 3, 6)
+                                                                        for v in ("view0", "view1"))
+    for i, it in share:
+        assert torch.equal(it["view1"]["image"], items[i]["view1"]["image"])
+    both = HostImageFeeder(raw, conf, depth=2)
+    a, b = iter(both), both.shard(0, 2)
+    mixed = [next(a), next(b)[1], next(a), next(b)[1], next(a)]
+    for it, i in zip(mixed, (0, 0, 1, 2, 2)):
+        assert torch.equal(it["view0"]["image"], items[i]["view0"]["image"]) and torch.equal(it["view0"]["scales"], items[i]["view0"]["scales"])
 
 
 @pytest.mark.gpu
