@@ -53,12 +53,12 @@ PAIR_FLOPS_EXECUTED = 2 * (2504 * 4096 * 600 + 4.0 / 9.0 * 28.31e9 + 0.79e9) + 7
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
-PMC_SUMMARIES = ("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json")  # newest first
+PMC_SUMMARIES = ("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json")  # newest first
 
 
 def pmc_traffic_bytes(kernel_prefix):
     """(HBM bytes per launch, file) of a kernel from the committed rocprofv3 --pmc passes of this same default
-    command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py, tools/profile_r05.sh).
+    command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; tools/pmc_summary.py, tools/profile_r06.sh).
     PMC counters cannot be collected from inside the process, so the figure is read from profiles/; (None, None)
     if absent."""
     for name in PMC_SUMMARIES:
