@@ -2,16 +2,13 @@
 (reference gluefactory/datasets/hpatches.py:23-35 `read_homography`, :38-77 sequence list, :94-112 items) and of the
 file decode it relies on (gluefactory/utils/image.py:135-161: `cv2.imread` -> RGB uint8 -> float / 255).
 
-HPatches ships binary PPM files (`<seq>/1.ppm` .. `6.ppm`) and plain-text 3x3 homographies (`<seq>/H_1_<q>`).  A binary
-PPM / PGM is a short text header followed by the raw samples, so reading it needs no image library and is exact by
-construction: the bytes of the file ARE the decoded image (cv2 / PIL are absent in this image).  `HPatches` lists the
-pairs exactly as the reference's dataset does and yields RAW items -- decoded uint8 images in (pinned) host memory plus
-`H_0to1`, `scene`, `idx`, `is_illu`, `name` -- for `image_preprocessor.HostImageFeeder`, which copies them to the GPU and
-does the reference's ImagePreprocessor work there.  No download: the reference fetches the archive when the directory
-is missing (hpatches.py:57,79-88); here a missing directory is an error.
-
-Not pinned against cv2 (absent): the GREY decode of a COLOUR file (`grayscale=True`, not the evaluation's default,
-hpatches.py:43) uses the 14-bit fixed-point weights OpenCV documents for BGR->GRAY; 16-bit files are refused.
+HPatches ships binary PPM files (`<seq>/1.ppm` .. `6.ppm`) and plain-text 3x3 homographies (`<seq>/H_1_<q>`); the
+files are decoded by `image_io.read_image` (a binary PPM is raw samples behind a text header: exact by construction, no
+image library involved).  `HPatches` lists the pairs exactly as the reference's dataset does and yields RAW items --
+decoded uint8 images in (pinned) host memory plus `H_0to1`, `scene`, `idx`, `is_illu`, `name` -- for
+`image_preprocessor.HostImageFeeder`, which copies them to the GPU and does the reference's ImagePreprocessor work there.
+No download: the reference fetches the archive when the directory is missing (hpatches.py:57,79-88); here a missing
+directory is an error.
 """
 import os
 from pathlib import Path
@@ -20,61 +17,9 @@ import numpy as np
 import torch
 
 from .base_model import merge
+from .image_io import read_image, read_ppm  # noqa: F401  (read_ppm re-exported: the files HPatches ships)
 from .image_preprocessor import DEFAULT_CONF as PREPROCESSING_DEFAULTS
 from .image_preprocessor import HostImageFeeder, ImagePreprocessor
-
-
-def _header_tokens(buf: bytes, count: int):
-    """The first `count` whitespace-separated header tokens of a netpbm file ('#' starts a comment that runs to the end
-    of the line) and the offset of the byte after the single whitespace that ends the last one."""
-    tokens, pos, n = [], 0, len(buf)
-    while len(tokens) < count:
-        while pos < n and (buf[pos:pos + 1].isspace() or buf[pos:pos + 1] == b"#"):
-            if buf[pos:pos + 1] == b"#":
-                while pos < n and buf[pos:pos + 1] not in (b"\n", b"\r"):
-                    pos += 1
-            else:
-                pos += 1
-        start = pos
-        while pos < n and not buf[pos:pos + 1].isspace() and buf[pos:pos + 1] != b"#":
-            pos += 1
-        if start == pos:
-            raise IOError("truncated netpbm header")
-        tokens.append(buf[start:pos])
-    return tokens, pos + 1  # exactly one whitespace byte separates the header from the raster
-
-
-def read_ppm(path, grayscale: bool = False) -> np.ndarray:
-    """Binary (P6 / P5) or plain (P3 / P2) PPM / PGM file -> uint8 array, [H,W,3] RGB or, with `grayscale`, [H,W] --
-    what `read_image` returns (gluefactory/utils/image.py:135-146: cv2.imread + BGR->RGB flip, or IMREAD_GRAYSCALE).
-    A grey file read as colour has its channel repeated three times, as cv2.IMREAD_COLOR does."""
-    path = Path(path)
-    if not path.exists():
-        raise FileNotFoundError(f"No image at path {path}.")
-    buf = path.read_bytes()
-    magic = buf[:2]
-    if magic not in (b"P6", b"P5", b"P3", b"P2"):
-        raise IOError(f"Could not read image at {path}.")  # the reference's error for a file cv2 cannot decode
-    (_, w, h, maxval), off = _header_tokens(buf, 4)
-    w, h, maxval = int(w), int(h), int(maxval)
-    if maxval != 255:
-        raise NotImplementedError(f"{path}: maxval {maxval}; only 8-bit files (maxval 255) are read")
-    c = 3 if magic in (b"P6", b"P3") else 1
-    if magic in (b"P6", b"P5"):
-        if len(buf) - off < h * w * c:
-            raise IOError(f"Could not read image at {path}.")
-        img = np.frombuffer(buf, np.uint8, h * w * c, off).reshape(h, w, c)
-    else:
-        vals = np.array(buf[off - 1:].split()[: h * w * c], dtype=np.int64)
-        if vals.size != h * w * c:
-            raise IOError(f"Could not read image at {path}.")
-        img = vals.astype(np.uint8).reshape(h, w, c)
-    if grayscale:
-        if c == 1:
-            return np.ascontiguousarray(img[..., 0])
-        r, g, b = (img[..., i].astype(np.int32) for i in range(3))
-        return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)  # OpenCV's 14-bit BGR2GRAY weights
-    return np.repeat(img, 3, axis=2) if c == 1 else img.copy()  # a writable array of its own (frombuffer views the file buffer)
 
 
 def read_homography(path) -> np.ndarray:
@@ -136,7 +81,7 @@ class HPatches:
         return np.diag([np.float32(size[1] / w), np.float32(size[0] / h), 1.0]).astype(np.float64)
 
     def _read(self, seq, idx):
-        img = torch.from_numpy(read_ppm(self.root / seq / f"{idx}.ppm", self.conf["grayscale"]))
+        img = torch.from_numpy(read_image(self.root / seq / f"{idx}.ppm", self.conf["grayscale"]))
         if self.conf["pin_memory"] and torch.cuda.is_available():
             img = img.pin_memory()
         return img

@@ -168,3 +168,27 @@ def test_export_from_an_hpatches_directory(tmp_path):
         for k in keys:
             assert np.array_equal(rec[k], from_files[name][k]), (name, k)
     assert sum(int((r["matches0"] >= 0).sum()) for r in from_files.values()) > 10 * 50
+
+
+def test_read_image_png_and_float_conversion(tmp_path, golden):
+    """`read_image` / `load_image` on a PNG (the reference's assets are PNGs: assets/boat1.png; lossless, so the decode
+    returns the encoder's pixels) and the float conversion of `numpy_image_to_torch` (image.py:135-161)."""
+    PIL = pytest.importorskip("PIL.Image")
+    from glue_factory_colon_amd import image_io
+
+    rgb = golden("boat_native")["image0"].numpy()  # the reference's boat1.png as decoded uint8 RGB [680, 850, 3]
+    PIL.fromarray(rgb).save(tmp_path / "boat1.png")
+    back = image_io.read_image(tmp_path / "boat1.png")
+    assert back.dtype == np.uint8 and np.array_equal(back, rgb)
+    g = image_io.read_image(tmp_path / "boat1.png", grayscale=True)
+    assert g.shape == rgb.shape[:2] and np.abs(g.astype(np.float64) - rgb.astype(np.float64) @ [0.299, 0.587, 0.114]).max() <= 0.51
+    PIL.fromarray(rgb[..., 1]).save(tmp_path / "grey.png")
+    assert np.array_equal(image_io.read_image(tmp_path / "grey.png", grayscale=True), rgb[..., 1])
+    assert np.array_equal(image_io.read_image(tmp_path / "grey.png")[..., 2], rgb[..., 1])
+    t = image_io.load_image(tmp_path / "boat1.png")
+    assert t.dtype == torch.float32 and t.shape == (3, 680, 850)
+    assert torch.equal(t, torch.tensor(rgb.transpose(2, 0, 1) / 255.0, dtype=torch.float))
+    assert image_io.load_image(tmp_path / "grey.png", grayscale=True).shape == (1, 680, 850)
+    (tmp_path / "junk.png").write_bytes(b"\x89PNG\r\n\x1a\n" + bytes(40))
+    with pytest.raises(IOError, match="Could not read image"):
+        image_io.read_image(tmp_path / "junk.png")
