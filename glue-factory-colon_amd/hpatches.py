@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .base_model import merge
-from .image_io import read_image, read_ppm  # noqa: F401  (read_ppm re-exported: the files HPatches ships)
+from .image_io import image_size, read_image, read_ppm  # noqa: F401  (read_ppm re-exported: the files HPatches ships)
 from .image_preprocessor import DEFAULT_CONF as PREPROCESSING_DEFAULTS
 from .image_preprocessor import HostImageFeeder, ImagePreprocessor
 
@@ -100,6 +100,23 @@ class HPatches:
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
+
+    def meta(self, idx):
+        """Pair `idx` without its pixels (file headers only): what the evaluation needs beside the cached predictions
+        (eval/hpatches.py:125-160 reads `H_0to1`, `name`, `scene`, `view0.image_size` and, through CacheLoader, the views'
+        `scales`).  Un-batched, on the host: `H_0to1` [3,3] float32, `scales` / `image_size` [2] float32."""
+        seq, q_idx, is_illu = self.items[idx]
+        views, T = {}, []
+        for tag, i in (("view0", 1), ("view1", q_idx)):
+            h, w = image_size(self.root / seq / f"{i}.ppm")
+            size = (h, w) if self.preprocessor.conf["resize"] is None else tuple(self.preprocessor.get_new_image_size(h, w))
+            T.append(self._transform(h, w))
+            views[tag] = {"scales": torch.tensor([size[1] / w, size[0] / h], dtype=torch.float32),
+                          "image_size": torch.tensor([float(size[1]), float(size[0])]),
+                          "original_image_size": torch.tensor([float(w), float(h)])}
+        H = T[1] @ read_homography(self.root / seq / f"H_1_{q_idx}") @ np.linalg.inv(T[0])
+        return {"H_0to1": torch.from_numpy(H.astype(np.float32)), "scene": seq, "idx": idx, "is_illu": is_illu,
+                "name": f"{seq}/{idx}.ppm", **views}
 
     def feeder(self, device="cuda", depth=16, keep=4):
         """The loader for `export_predictions`: items preprocessed on the GPU; the sequence's image 1 -- view 0 of all

@@ -70,6 +70,21 @@ def read_ppm(path, grayscale: bool = False) -> np.ndarray:
     return np.repeat(img, 3, axis=2) if c == 1 else img.copy()  # a writable array of its own (frombuffer views the file buffer)
 
 
+def image_size(path):
+    """(height, width) of an image file from its header alone (PPM / PGM here, other formats through Pillow's lazy open)."""
+    path = Path(path)
+    if not path.exists():
+        raise FileNotFoundError(f"No image at path {path}.")
+    with open(path, "rb") as f:
+        head = f.read(512)
+    if head[:2] in (b"P6", b"P5", b"P3", b"P2"):
+        (_, w, h), _ = _header_tokens(head, 3)
+        return int(h), int(w)
+    from PIL import Image
+    with Image.open(path) as im:
+        return im.height, im.width
+
+
 def _grey(rgb: np.ndarray) -> np.ndarray:
     r, g, b = (rgb[..., i].astype(np.int32) for i in range(3))
     return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)  # OpenCV's 14-bit BGR2GRAY weights

@@ -115,6 +115,14 @@ def test_pair_list_and_raw_items(tmp_path):
     assert it["H_0to1"].shape == (1, 3, 3) and it["H_0to1"].dtype == torch.float32
     assert np.array_equal(it["H_0to1"][0].numpy(), want)
     assert len(list(iter(ds))) == 15
+    # meta(): the same pair from the file headers alone (what the evaluation reads beside the cached predictions)
+    m = ds.meta(6)
+    assert m["name"] == it["name"] and m["scene"] == "v_bark" and torch.equal(m["H_0to1"], it["H_0to1"][0])
+    for tag, img in (("view0", imgs[0]), ("view1", imgs[2])):
+        h, w = img.shape[:2]
+        nh, nw = pp.get_new_image_size(h, w)
+        assert m[tag]["image_size"].tolist() == [nw, nh] and m[tag]["original_image_size"].tolist() == [w, h]
+        assert torch.equal(m[tag]["scales"], torch.tensor([nw / w, nh / h], dtype=torch.float32))
     assert hpatches.HPatches.view_key(it, 0) == ("v_bark", 1) and hpatches.HPatches.view_key(it, 1) is None
     assert hpatches.HPatches.view_key({"scene": ["v_bark"]}, 0) == ("v_bark", 1)  # collated form
     with pytest.raises(FileNotFoundError, match="no download"):
@@ -168,6 +176,64 @@ def test_export_from_an_hpatches_directory(tmp_path):
         for k in keys:
             assert np.array_equal(rec[k], from_files[name][k]), (name, k)
     assert sum(int((r["matches0"] >= 0).sum()) for r in from_files.values()) > 10 * 50
+
+
+@pytest.mark.gpu
+def test_hpatches_pipeline_from_a_directory(tmp_path):
+    """eval_hpatches.HPatchesPipeline (gluefactory/eval/hpatches.py:98-176 without the RANSAC estimators): directory ->
+    predictions.h5 (reference layout) -> per-pair match metrics + DLT error on the GPU -> the reference's summary keys.
+    The tree is two sequences whose pairs are crops of one canvas displaced by a known shift, so the written H_1_q is
+    the true homography and the metrics have known-good values."""
+    from glue_factory_colon_amd import _hdf5, eval_hpatches, synthetic
+    from glue_factory_colon_amd.export_predictions import load_predictions
+
+    raw = synthetic.hpatches_like_host_images(10, seed=5200, pin=False, shared_view0=True)
+    root = tmp_path / "hpatches-sequences-release"
+    shapes = {}
+    for i, it in enumerate(raw):
+        seq = "v_" + it["scene"]
+        (root / seq).mkdir(parents=True, exist_ok=True)
+        if i % 5 == 0:
+            write_ppm(root / seq / "1.ppm", it["view0"]["image"].numpy())
+        write_ppm(root / seq / f"{i % 5 + 2}.ppm", it["view1"]["image"].numpy())
+        shapes[i] = (it["view0"]["image"].shape[:2], it["view1"]["image"].shape[:2])
+    # view 1 = the canvas displaced by (dx, dy) = (24 + 6 k, 16 + 4 k) canvas pixels, k = i % 5, each view up-sampled from
+    # its crop by its own factor: in ORIGINAL pixels x1 = (x0 / u0 - d) * u1 (synthetic.hpatches_like_host_images)
+    from glue_factory_colon_amd.synthetic import HPATCHES_LIKE_ORIGINALS, HPATCHES_LIKE_SHAPES
+    for i in range(10):
+        j0, j1 = (i // 5) % 5, (i * 2 + 1) % 5
+        u0x = HPATCHES_LIKE_ORIGINALS[j0][1] / HPATCHES_LIKE_SHAPES[j0][1]
+        u0y = HPATCHES_LIKE_ORIGINALS[j0][0] / HPATCHES_LIKE_SHAPES[j0][0]
+        u1x = HPATCHES_LIKE_ORIGINALS[j1][1] / HPATCHES_LIKE_SHAPES[j1][1]
+        u1y = HPATCHES_LIKE_ORIGINALS[j1][0] / HPATCHES_LIKE_SHAPES[j1][0]
+        dx, dy = 24 + 6 * (i % 5), 16 + 4 * (i % 5)
+        H = np.array([[u1x / u0x, 0, -dx * u1x], [0, u1y / u0y, -dy * u1y], [0, 0, 1.0]])
+        (root / ("v_" + raw[i]["scene"]) / f"H_1_{i % 5 + 2}").write_text("\n".join(" ".join(f"{v:.10g}" for v in row) for row in H) + "\n")
+    pipe = eval_hpatches.HPatchesPipeline({"data_dir": str(root)}, pair_batch=8)
+    model = eval_hpatches.build_model("synthetic", "synthetic", official=False, max_num_keypoints=512).cuda()
+    summaries, results = pipe.run(tmp_path / "exp", model)
+    pred_file = tmp_path / "exp" / "predictions.h5"
+    assert pred_file.exists() and len(load_predictions(pred_file)) == 10
+    if _hdf5.available():
+        assert open(pred_file, "rb").read(4) == b"\x89HDF"  # the reference's container
+    assert results["names"] == [f"v_{it['scene']}/{i}.ppm" for i, it in enumerate(raw)]
+    for key in ("prec@1px", "prec@3px", "num_matches", "num_keypoints", "gt_match_recall@3px", "gt_match_precision@3px",
+                "H_error_dlt"):
+        assert f"mean_{key}" in summaries and f"med_{key}" in summaries, key
+    for th in (1, 3, 5):
+        assert f"H_error_dlt@{th}px" in summaries
+    # The name-seeded matcher only finds the displacement its weights were calibrated on (k = 0: the first pair of each
+    # sequence, ~340 matches; the larger shifts give ~10): there the matches follow the written homography -- precise at
+    # 3 px, and the weighted DLT recovers it to well under a pixel.  The other pairs exercise the few-matches side.
+    for i in (0, 5):
+        assert results["num_matches"][i] > 200 and results["prec@3px"][i] > 0.95, (i, results["prec@3px"][i])
+        assert results["H_error_dlt"][i] < 0.5, (i, results["H_error_dlt"][i])
+    assert all(np.isfinite(results["prec@3px"])) and len(results["H_error_dlt"]) == 10
+    assert summaries["mean_prec@3px"] == round(float(np.mean(results["prec@3px"])), 3)
+    assert summaries["H_error_dlt@1px"] >= 0.19  # two of ten pairs below a pixel: AUC@1px >= 0.2 x (1 - err) (tools.py:137-149)
+    # a second run reuses the prediction file (no model needed), as the reference does without --overwrite
+    again, _ = pipe.run(tmp_path / "exp", None)
+    assert again == summaries
 
 
 def test_read_image_png_and_float_conversion(tmp_path, golden):

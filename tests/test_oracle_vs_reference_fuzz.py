@@ -153,3 +153,28 @@ def test_lightglue_oracle_equals_reference_on_random_key_point_sets(ref):
             # (the restatement and the reference associate the attention / soft-max sums differently: measured 1.9e-5)
             assert ((la_p - la_o).abs() / (1 + la_o.abs())).max().item() <= 5e-5
             assert (p["ref_descriptors0"] - o["ref_descriptors0"]).abs().max().item() <= 1e-4
+
+
+def test_host_side_restatements_against_the_reference(ref, tmp_path):
+    """Host logic restated in the package against the reference's own function on random inputs: the AUC of the
+    evaluation summaries (utils/tools.py:137-149).  (`read_homography`, datasets/hpatches.py:23-35, cannot be imported
+    here -- its module needs cv2 -- and is tested on files the test writes, tests/test_hpatches_reader.py.)"""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(HERE, "golden", "_standins"))
+    sys.path.insert(0, REF)
+    try:
+        from gluefactory.utils.tools import cal_error_auc as ref_auc
+    finally:
+        sys.path.remove(REF)
+        sys.path.remove(os.path.join(HERE, "golden", "_standins"))
+    from glue_factory_colon_amd.eval_hpatches import cal_error_auc
+
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 540):
+        errors = (rng.gamma(1.5, 2.0, n)).tolist()
+        if n == 540:
+            errors[5] = float("inf")  # a pair with fewer than four matches (eval/utils.py:289-291)
+            errors[9] = 3.0           # exactly on a threshold
+        for ths in ([1, 3, 5], [5, 10, 20]):
+            assert [float(a) for a in cal_error_auc(errors, ths)] == [float(a) for a in ref_auc(errors, ths)], (n, ths)
