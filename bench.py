@@ -599,7 +599,7 @@ def rehearse_cpu(args):
         torch.distributed.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        time.sleep(0.001 * (1 + rank))  # rank r is r times slower: the per-rank table must show it
+        time.sleep(0.01 * (1 + rank))  # rank r is r times slower: the per-rank table must show it
     busy = time.perf_counter() - t0
     if world > 1:
         torch.distributed.barrier()

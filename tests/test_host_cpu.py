@@ -504,7 +504,8 @@ def test_bench_multiprocess_plumbing_rehearsal_world8():
         assert all(field in row for row in per), field
     assert [row["matches_last_step"] for row in per] == [10 + r for r in range(8)]
     assert per[7]["busy_s"] > 2 * per[0]["busy_s"]  # the rehearsal makes rank r slower with r: visible per rank ...
-    assert all(row["elapsed_s"] >= per[7]["busy_s"] * 0.99 for row in per)  # ... while every rank waited for the slowest
+    # ... while every rank waited for the slowest (each rank's clock starts when IT leaves the opening barrier: allow skew)
+    assert all(row["elapsed_s"] >= per[7]["busy_s"] * 0.9 for row in per)
     summ = out["config"]["per_rank_summary"]
     assert summ["busy_s"][0] == per[0]["busy_s"] and summ["busy_s"][2] == per[7]["busy_s"]
     assert summ["busy_s"][0] <= summ["busy_s"][1] <= summ["busy_s"][2] and "probe_tflops" not in summ  # no GPU here

@@ -12,6 +12,7 @@ chip by the profiler).  Derived per kernel:
                               other VALU instruction 3.2 (low) .. 4.9 (high) -> [pessimistic, optimistic]
   mfma_util_pct               SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024): what was measured
   wait_share_pct              SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES: share of wave-resident time spent waiting on any counter
+Kernels without MFMAs get `valu_busy_pct` instead: vector instructions x 4 cycles / (kernel cycles x 1024 SIMDs).
 A kernel whose mfma_util is at its issue ceiling is issue-bound (fewer VALU instructions help); one far below it is
 stall-bound (wait_share says how much of the waves' time is waiting)."""
 import collections
@@ -23,7 +24,7 @@ import sys
 SIMDS = 1024
 MFMA_CYCLES = 64
 KEEP = ("attention_kernel", "stem_wino43_kernel", "conv3x3_wino_kernel", "gemm_nt_kernel", "gemm_rows512", "gemm_mlp",
-        "det_head_kernel", "conv3x3", "nms_stream", "assign_")
+        "det_head_kernel", "conv3x3", "nms_stream", "assign_", "select_kernel", "sample_kernel", "posenc_kernel")
 
 
 def read(dirs):
@@ -45,6 +46,18 @@ def main(dirs):
         m = {name: sum(v) / len(v) for name, v in c.items()}
         mfma = m.get("SQ_INSTS_MFMA", 0.0)
         if mfma <= 0:
+            # a kernel without matrix work (NMS, select, sampling, assignment tail): how busy is the VECTOR unit?  A wave64
+            # instruction occupies a SIMD's 16 lanes for 4 cycles; kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs
+            gui = m.get("GRBM_GUI_ACTIVE", 0.0)
+            if gui and m.get("SQ_INSTS_VALU"):
+                out[k] = {"launches": len(c.get("SQ_INSTS_VALU", [])),
+                          "insts_per_launch": {n.replace("SQ_INSTS_", "").lower(): round(v) for n, v in sorted(m.items())
+                                               if n.startswith("SQ_INSTS_")},
+                          "valu_busy_pct": round(100 * m["SQ_INSTS_VALU"] * 4 / (gui / 8 * SIMDS), 1),
+                          "lds_per_valu": round(m.get("SQ_INSTS_LDS", 0.0) / m["SQ_INSTS_VALU"], 3),
+                          "kernel_cycles": round(gui / 8)}
+                if m.get("SQ_WAVE_CYCLES"):
+                    out[k]["wait_share_pct"] = round(100 * m.get("SQ_WAIT_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"], 1)
             continue
         valu = max(m.get("SQ_INSTS_VALU", 0.0) - mfma, 0.0)
         trans = m.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
