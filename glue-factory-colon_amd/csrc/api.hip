@@ -19,7 +19,7 @@ int gfc_assign_filter_fused(float* scores, const float* z0, const float* z1, int
 #ifndef GFC_SOURCE_HASH
 #define GFC_SOURCE_HASH "unknown"
 #endif
-extern "C" const char* gfc_version(void) { return "gfc_amd 0.4.0 (gfx950, fp32 MFMA) src " GFC_SOURCE_HASH; }
+extern "C" const char* gfc_version(void) { return "gfc_amd 0.6.0 (gfx950, fp32 MFMA) src " GFC_SOURCE_HASH; }
 
 #define GFC_TRY(expr)            \
   do {                           \
