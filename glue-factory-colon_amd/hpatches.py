@@ -81,10 +81,18 @@ class HPatches:
         return np.diag([np.float32(size[1] / w), np.float32(size[0] / h), 1.0]).astype(np.float64)
 
     def _read(self, seq, idx):
-        img = torch.from_numpy(read_image(self.root / seq / f"{idx}.ppm", self.conf["grayscale"]))
-        if self.conf["pin_memory"] and torch.cuda.is_available():
-            img = img.pin_memory()
-        return img
+        """Decoded uint8 image as a host tensor; with `pin_memory` the file is read straight into pinned memory (no
+        pageable intermediate, no copy by torch's CPU thread pool)."""
+        if not (self.conf["pin_memory"] and torch.cuda.is_available()):
+            return torch.from_numpy(read_image(self.root / seq / f"{idx}.ppm", self.conf["grayscale"]))
+        holder = []
+
+        def alloc(nbytes):
+            holder.append(torch.empty(nbytes, dtype=torch.uint8, pin_memory=True))
+            return holder[0].numpy()
+
+        arr = read_image(self.root / seq / f"{idx}.ppm", self.conf["grayscale"], alloc)
+        return holder[0].view(arr.shape)
 
     def __getitem__(self, idx):
         """Raw item of pair `idx` (hpatches.py:98-112), already in the collated shapes a batch-1 DataLoader gives:
@@ -118,14 +126,56 @@ class HPatches:
         return {"H_0to1": torch.from_numpy(H.astype(np.float32)), "scene": seq, "idx": idx, "is_illu": is_illu,
                 "name": f"{seq}/{idx}.ppm", **views}
 
-    def feeder(self, device="cuda", depth=16, keep=4):
+    def feeder(self, device="cuda", depth=64, keep=4, num_workers=2):
         """The loader for `export_predictions`: items preprocessed on the GPU; the sequence's image 1 -- view 0 of all
         five of its pairs -- is copied and resized once (`view_key`, also what `export_predictions(view_key=...)` takes
-        to extract it once)."""
-        return HostImageFeeder(self, self.conf["preprocessing"], device=device, depth=depth, view_key=self.view_key,
-                               keep=keep)
+        to extract it once).  num_workers > 0: the files are read `num_workers` at a time by reader THREADS, ahead of the
+        consumer (a file read releases the interpreter lock and lands straight in pinned memory, so threads do what the
+        reference's 16 loader processes do, eval/hpatches.py:47, without shipping 7 MB items between processes: measured
+        140 pairs/s through a DataLoader with 8 worker processes, 1770 from one thread, `profiles/r06_hpatches_from_files.txt`);
+        under torch.distributed every rank reads only its own share of the list.  depth: items copied ahead of the
+        consumer -- at least twice the consumer's pair batch, or staging a batch waits for its own copies."""
+        return HPatchesFeeder(self, device=device, depth=depth, keep=keep, num_workers=int(num_workers))
+
+    def raw_loader(self, indices=None, num_workers=0, prefetch=48):
+        """Raw items in list order (or of `indices`); num_workers > 0: read by that many threads, up to `prefetch` items
+        ahead of the consumer, yielded in order."""
+        idx = list(range(len(self)) if indices is None else indices)
+        if num_workers <= 0:
+            for i in idx:
+                yield self[i]
+            return
+        import itertools
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(num_workers, thread_name_prefix="gfc-hpatches-read") as ex:
+            it = iter(idx)
+            pending = deque(ex.submit(self.__getitem__, i) for i in itertools.islice(it, max(1, int(prefetch))))
+            while pending:
+                item = pending.popleft().result()
+                nxt = next(it, None)
+                if nxt is not None:
+                    pending.append(ex.submit(self.__getitem__, nxt))
+                yield item
 
     @staticmethod
     def view_key(raw, i):
         scene = raw["scene"][0] if isinstance(raw["scene"], (list, tuple)) else raw["scene"]
         return (scene, 1) if i == 0 else None
+
+
+class HPatchesFeeder(HostImageFeeder):
+    """`HostImageFeeder` over an `HPatches` list whose files are read ahead of the consumer by reader threads."""
+
+    def __init__(self, dataset, device="cuda", depth=64, keep=4, num_workers=2):
+        super().__init__(dataset, dataset.conf["preprocessing"], device=device, depth=depth, view_key=dataset.view_key,
+                         keep=keep)
+        self.dataset, self.num_workers = dataset, num_workers
+
+    def __iter__(self):
+        return self._iterate(self.dataset.raw_loader(None, self.num_workers))
+
+    def shard(self, rank, world, group=1):
+        from .sharding import round_robin_shard
+        idx = list(round_robin_shard(len(self.dataset), int(rank), int(world), max(1, int(group))))
+        return zip(idx, self._iterate(self.dataset.raw_loader(idx, self.num_workers)))

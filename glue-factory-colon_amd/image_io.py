@@ -38,22 +38,35 @@ def _header_tokens(buf: bytes, count: int):
     return tokens, pos + 1  # exactly one whitespace byte separates the header from the raster
 
 
-def read_ppm(path, grayscale: bool = False) -> np.ndarray:
+def read_ppm(path, grayscale: bool = False, alloc=None) -> np.ndarray:
     """Binary (P6 / P5) or plain (P3 / P2) PPM / PGM file -> uint8 array, [H,W,3] RGB or, with `grayscale`, [H,W] --
     what `read_image` returns (gluefactory/utils/image.py:135-146: cv2.imread + BGR->RGB flip, or IMREAD_GRAYSCALE).
-    A grey file read as colour has its channel repeated three times, as cv2.IMREAD_COLOR does."""
+    A grey file read as colour has its channel repeated three times, as cv2.IMREAD_COLOR does.
+    alloc (optional): `alloc(nbytes) -> writable uint8 array` for the result (e.g. a view of pinned host memory); a binary
+    file whose layout is the result's is then read STRAIGHT into it (`readinto`: one pass over the bytes, no copy, and the
+    interpreter lock is released while the file is read)."""
     path = Path(path)
     if not path.exists():
         raise FileNotFoundError(f"No image at path {path}.")
-    buf = path.read_bytes()
-    magic = buf[:2]
-    if magic not in (b"P6", b"P5", b"P3", b"P2"):
-        raise IOError(f"Could not read image at {path}.")  # the reference's error for a file cv2 cannot decode
-    (_, w, h, maxval), off = _header_tokens(buf, 4)
-    w, h, maxval = int(w), int(h), int(maxval)
-    if maxval != 255:
-        raise NotImplementedError(f"{path}: maxval {maxval}; only 8-bit files (maxval 255) are read")
-    c = 3 if magic in (b"P6", b"P3") else 1
+    with open(path, "rb") as f:
+        head = f.read(512)
+        magic = head[:2]
+        if magic not in (b"P6", b"P5", b"P3", b"P2"):
+            raise IOError(f"Could not read image at {path}.")  # the reference's error for a file cv2 cannot decode
+        (_, w, h, maxval), off = _header_tokens(head, 4)
+        w, h, maxval = int(w), int(h), int(maxval)
+        if maxval != 255:
+            raise NotImplementedError(f"{path}: maxval {maxval}; only 8-bit files (maxval 255) are read")
+        c = 3 if magic in (b"P6", b"P3") else 1
+        direct = (magic == b"P6" and not grayscale) or (magic == b"P5" and grayscale)
+        if direct:  # the raster IS the result
+            out = np.empty(h * w * c, np.uint8) if alloc is None else alloc(h * w * c)
+            f.seek(off)
+            if f.readinto(memoryview(out)) != h * w * c:
+                raise IOError(f"Could not read image at {path}.")
+            return out.reshape((h, w, 3) if c == 3 else (h, w))
+        f.seek(0)
+        buf = f.read()
     if magic in (b"P6", b"P5"):
         if len(buf) - off < h * w * c:
             raise IOError(f"Could not read image at {path}.")
@@ -64,10 +77,14 @@ def read_ppm(path, grayscale: bool = False) -> np.ndarray:
             raise IOError(f"Could not read image at {path}.")
         img = vals.astype(np.uint8).reshape(h, w, c)
     if grayscale:
-        if c == 1:
-            return np.ascontiguousarray(img[..., 0])
-        return _grey(img)
-    return np.repeat(img, 3, axis=2) if c == 1 else img.copy()  # a writable array of its own (frombuffer views the file buffer)
+        res = img[..., 0] if c == 1 else _grey(img)
+    else:
+        res = np.repeat(img, 3, axis=2) if c == 1 else img
+    if alloc is None:
+        return np.ascontiguousarray(res).copy() if not res.flags.writeable else np.ascontiguousarray(res)
+    out = alloc(res.size).reshape(res.shape)
+    out[...] = res
+    return out
 
 
 def image_size(path):
@@ -90,15 +107,16 @@ def _grey(rgb: np.ndarray) -> np.ndarray:
     return ((r * 4899 + g * 9617 + b * 1868 + (1 << 13)) >> 14).astype(np.uint8)  # OpenCV's 14-bit BGR2GRAY weights
 
 
-def read_image(path, grayscale: bool = False) -> np.ndarray:
-    """Image file -> uint8 [H,W,3] RGB, or [H,W] with `grayscale` (gluefactory/utils/image.py:135-146, same errors)."""
+def read_image(path, grayscale: bool = False, alloc=None) -> np.ndarray:
+    """Image file -> uint8 [H,W,3] RGB, or [H,W] with `grayscale` (gluefactory/utils/image.py:135-146, same errors).
+    alloc: see `read_ppm` (honoured for every format)."""
     path = Path(path)
     if not path.exists():
         raise FileNotFoundError(f"No image at path {path}.")
     with open(path, "rb") as f:
         magic = f.read(2)
     if magic in (b"P6", b"P5", b"P3", b"P2"):
-        return read_ppm(path, grayscale)
+        return read_ppm(path, grayscale, alloc)
     try:
         from PIL import Image
     except ImportError as e:  # pragma: no cover -- Pillow is part of the image
@@ -112,8 +130,12 @@ def read_image(path, grayscale: bool = False) -> np.ndarray:
     except Exception as e:  # noqa: BLE001 -- whatever the decoder raises: the reference's error
         raise IOError(f"Could not read image at {path}.") from e
     if grayscale:
-        return arr.copy() if grey_file else _grey(arr)
-    return np.repeat(arr[..., None], 3, axis=2) if grey_file else arr.copy()
+        res = arr if grey_file else _grey(arr)
+    else:
+        res = np.repeat(arr[..., None], 3, axis=2) if grey_file else arr
+    out = np.empty(res.shape, np.uint8) if alloc is None else alloc(res.size).reshape(res.shape)
+    out[...] = res
+    return out
 
 
 def numpy_image_to_torch(image: np.ndarray) -> torch.Tensor:

@@ -125,6 +125,14 @@ def test_pair_list_and_raw_items(tmp_path):
         assert torch.equal(m[tag]["scales"], torch.tensor([nw / w, nh / h], dtype=torch.float32))
     assert hpatches.HPatches.view_key(it, 0) == ("v_bark", 1) and hpatches.HPatches.view_key(it, 1) is None
     assert hpatches.HPatches.view_key({"scene": ["v_bark"]}, 0) == ("v_bark", 1)  # collated form
+    # the same raw items from DataLoader worker processes (decode in parallel), whole list and a rank's share
+    for indices in (None, [1, 6, 11]):
+        got = list(ds.raw_loader(indices, num_workers=2))
+        want = [ds[i] for i in (range(len(ds)) if indices is None else indices)]
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert a["name"] == b["name"] and a["scene"] == b["scene"] and torch.equal(a["H_0to1"], b["H_0to1"])
+            assert torch.equal(a["view0"]["image"], b["view0"]["image"]) and torch.equal(a["view1"]["image"], b["view1"]["image"])
     with pytest.raises(FileNotFoundError, match="no download"):
         hpatches.HPatches({"data_dir": str(tmp_path / "absent")})
     os.environ["GFC_DATA_PATH"] = str(tmp_path)
@@ -169,6 +177,16 @@ def test_export_from_an_hpatches_directory(tmp_path):
     assert sorted(from_files) == sorted(f"v_{it['scene']}/{i}.ppm" for i, it in enumerate(raw))
     # each sequence's image 1 travelled and was resized once
     assert feeder.h2d_bytes == sum(it["view1"]["image"].numel() for it in raw) + sum(raw[i]["view0"]["image"].numel() for i in (0, 5))
+    # files decoded by two DataLoader worker processes, and a rank's share of the list (shard): the same records
+    workers = ds.feeder(num_workers=2)
+    par = load_predictions(export_predictions(workers, pipeline(), tmp_path / "workers.npz", keys=keys, pair_batch=8,
+                                              view_key=ds.view_key))
+    assert list(par) == list(from_files)
+    for name, rec in par.items():
+        for k in keys:
+            assert np.array_equal(rec[k], from_files[name][k]), (name, k)
+    share = list(ds.feeder(num_workers=2).shard(1, 2, group=5))
+    assert [i for i, _ in share] == [5, 6, 7, 8, 9] and share[0][1]["name"] == [f"v_{raw[5]['scene']}/5.ppm"]
     direct_items = [{**it, "name": f"v_{it['scene']}/{i}.ppm"} for i, it in enumerate(raw)]
     direct = load_predictions(export_predictions(HostImageFeeder(direct_items, conf), pipeline(), tmp_path / "direct.npz",
                                                  keys=keys, pair_batch=8))
@@ -231,6 +249,13 @@ def test_hpatches_pipeline_from_a_directory(tmp_path):
     assert all(np.isfinite(results["prec@3px"])) and len(results["H_error_dlt"]) == 10
     assert summaries["mean_prec@3px"] == round(float(np.mean(results["prec@3px"])), 3)
     assert summaries["H_error_dlt@1px"] >= 0.19  # two of ten pairs below a pixel: AUC@1px >= 0.2 x (1 - err) (tools.py:137-149)
+    # the grouped evaluation = the reference's pair-by-pair loop through CacheLoader and the drop-in eval functions
+    pairwise = pipe.run_eval_pairwise(pred_file)
+    assert pairwise["names"] == results["names"] and pairwise["num_matches"] == results["num_matches"]
+    for key in (*eval_hpatches.eval_utils.RESULT_KEYS, "H_error_dlt"):
+        a, b = np.array(pairwise[key], dtype=np.float64), np.array(results[key], dtype=np.float64)
+        fin = np.isfinite(a)
+        assert np.array_equal(fin, np.isfinite(b)) and np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6), key
     # a second run reuses the prediction file (no model needed), as the reference does without --overwrite
     again, _ = pipe.run(tmp_path / "exp", None)
     assert again == summaries
