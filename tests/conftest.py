@@ -12,7 +12,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 # The CPU oracle (torch-CPU) is the checker of most GPU tests.  On the GPU box torch starts 128 threads on a 16-CPU share
 # of a 256-CPU host, and the oracle's matcher then takes 1.9 s per VGA pair instead of 0.43 s with 16 threads
-# (gpurun_out/r06_threads.log): bound the pool here and, through the environment, in the child processes tests start.
+# (profiles/r06_oracle_threads.txt): bound the pool here and, through the environment, in the child processes tests start.
 _THREADS = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count() or 1))
 torch.set_num_threads(_THREADS)
 os.environ.setdefault("OMP_NUM_THREADS", str(_THREADS))
