@@ -16,15 +16,6 @@
 
 #define GBK 32  // K granularity of the API (every variant's K tile divides it)
 
-#ifndef GEMM_ABL
-#define GEMM_ABL 0  // ablation builds with WRONG results (tools/ab_build.sh WORKTREE abl "-DGEMM_ABL=n"; profiles/r06_gemm_ablation.txt): 1 no K-loop barrier, 2 no staging writes to LDS, 4 no global loads of the following tiles, 8 the WEIGHT operand is neither loaded nor staged (activations still are)
-#endif
-#if GEMM_ABL & 1
-#define GEMM_KSYNC() do {} while (0)
-#else
-#define GEMM_KSYNC() __syncthreads()
-#endif
-
 struct GemmArgs {
   const float* A0;
   const float* A1;
@@ -45,7 +36,6 @@ struct GemmArgs {
   int wide_stores;  // every epilogue through the per-wave LDS transpose: float4 stores (runtime.h: GFC_GEMM_EPI)
   int stagger;      // first-round workgroups start (wave slot & 3) * stagger * 8128 cycles late (GFC_GEMM_STAGGER)
   int first_round;  // number of workgroups resident at once (4 per CU)
-  int wfrag;        // W is packed in MFMA-fragment order (gfc_pack_linear_frag): the weight operand bypasses LDS
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
   unsigned long long* stamps;  // diagnostic build (tools/micro/gemm_timeline.py): 8 words per wave
 #endif
@@ -301,13 +291,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x16 (&acc)[M
 //                    4x the workgroups, so that a [2048, 256] GEMM still covers the chip
 // LDS is double-buffered: one barrier per K tile, the next tile travels global -> VGPR -> LDS
 // underneath the MFMAs of the current one.
-// BD = true ("B direct", round 6): the weights come packed in MFMA-fragment order (pack_linear_frag_kernel:
-// [n tile of 32][k group of 8][lane][4]) and every wave loads the fragments of its own column tiles straight from L2 / L1
-// into registers, one k group ahead -- coalesced 1 KB per load; only the activation tile is staged through LDS, with a
-// 32-deep K tile at the LDS size the 16-deep two-operand tile had: half the staging writes, half the LDS reads, half the
-// barriers.  Same k order per accumulator: results bit-identical to the staged form.
-template <int NW, int MT, int BK, int MTN = MT, bool BD = false>
-__global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : ((BK == 16 || BD) ? 4 : 2)) void gemm_nt_kernel(GemmArgs g) {
+template <int NW, int MT, int BK, int MTN = MT>
+__global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : (BK == 16 ? 4 : 2)) void gemm_nt_kernel(GemmArgs g) {
   constexpr int T = 128 * NW;        // threads
   constexpr int GBM = 64 * MT;       // tile height (2 waves)
   constexpr int BN = 32 * MTN * NW;  // tile width
@@ -316,7 +301,7 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : ((BK == 16 || BD) ? 4 
   constexpr int RPP = T / C4;        // rows staged per pass
   constexpr int NA = GBM / RPP;      // float4 of A per thread per K tile
   constexpr int NB = BN / RPP;       // float4 of W per thread per K tile
-  constexpr int TILE = (GBM + (BD ? 0 : BN)) * GLD;
+  constexpr int TILE = (GBM + BN) * GLD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
 
   const int tid = threadIdx.x;
@@ -393,13 +378,11 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : ((BK == 16 || BD) ? 4 
       areg2 = *reinterpret_cast<const float4*>(ab_ + ar2 * ld_);                                     \
       areg3 = *reinterpret_cast<const float4*>(ab_ + ar3 * ld_);                                     \
     }                                                                                                \
-    if (!(GEMM_ABL & 8) && !BD) {                                                                    \
     wreg0 = *reinterpret_cast<const float4*>(w0p + k0_);                                             \
     if constexpr (NB >= 2) wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                      \
     if constexpr (NB == 4) {                                                                         \
       wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                                           \
       wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                                           \
-    }                                                                                                \
     }                                                                                                \
   } while (0)
 #define GEMM_STORE_TILE(buf_)                                                                        \
@@ -412,13 +395,11 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : ((BK == 16 || BD) ? 4 
       *reinterpret_cast<float4*>(as_ + 2 * RPP * GLD) = areg2;                                       \
       *reinterpret_cast<float4*>(as_ + 3 * RPP * GLD) = areg3;                                       \
     }                                                                                                \
-    if (!(GEMM_ABL & 8) && !BD) {                                                                    \
     *reinterpret_cast<float4*>(bs_) = wreg0;                                                         \
     if constexpr (NB >= 2) *reinterpret_cast<float4*>(bs_ + RPP * GLD) = wreg1;                      \
     if constexpr (NB == 4) {                                                                         \
       *reinterpret_cast<float4*>(bs_ + 2 * RPP * GLD) = wreg2;                                       \
       *reinterpret_cast<float4*>(bs_ + 3 * RPP * GLD) = wreg3;                                       \
-    }                                                                                                \
     }                                                                                                \
   } while (0)
 
@@ -442,61 +423,10 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : ((BK == 16 || BD) ? 4 
   if (ktiles > 1) GEMM_LOAD_TILE(1);
   __syncthreads();
   GEMM_STAMP(1);
-  if constexpr (BD) {
-    // fragment stream of this wave: column tile (n0 / 32 + wn * MTN + nt), clamped to the last tile that exists (its
-    // columns beyond N are never stored), k group kg: 64 lanes x float4 = 1 KB, contiguous
-    const int nkg = (g.K0 + g.K1) / 8, last_nt = (g.N - 1) / 32;
-    const float4* wf[MTN];
-#pragma unroll
-    for (int nt = 0; nt < MTN; ++nt)
-      wf[nt] = reinterpret_cast<const float4*>(W) + ((size_t)min(n0 / 32 + wn * MTN + nt, last_nt) * nkg) * 64 + lane;
-    float4 bcur[MTN], bnext[MTN];
-#pragma unroll
-    for (int nt = 0; nt < MTN; ++nt) bnext[nt] = bcur[nt] = wf[nt][0];
-    for (int kt = 0; kt < ktiles; ++kt) {
-      // the first k group's look-ahead load goes out BEFORE the staging loads, so that waiting for it does not wait for them
-      if (kt * (BK / 8) + 1 < nkg) {
-#pragma unroll
-        for (int nt = 0; nt < MTN; ++nt) bnext[nt] = wf[nt][(size_t)(kt * (BK / 8) + 1) * 64];
-      }
-      if (kt + 1 < ktiles) {
-        GEMM_STORE_TILE((kt + 1) & 1);
-        if (kt + 2 < ktiles) GEMM_LOAD_TILE(kt + 2);
-      }
-      const float* ap = smem + (kt & 1) * TILE + a_off;
-#pragma unroll
-      for (int gk = 0; gk < BK / 8; ++gk) {
-        const int kg = kt * (BK / 8) + gk;
-        if (gk > 0 && kg + 1 < nkg) {
-#pragma unroll
-          for (int nt = 0; nt < MTN; ++nt) bnext[nt] = wf[nt][(size_t)(kg + 1) * 64];
-        }
-        float4 af[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) af[mt] = *reinterpret_cast<const float4*>(ap + mt * 32 * GLD + 8 * gk);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < MTN; ++nt) {
-            acc[mt][nt] = mfma32(af[mt].x, bcur[nt].x, acc[mt][nt]);
-            acc[mt][nt] = mfma32(af[mt].y, bcur[nt].y, acc[mt][nt]);
-            acc[mt][nt] = mfma32(af[mt].z, bcur[nt].z, acc[mt][nt]);
-            acc[mt][nt] = mfma32(af[mt].w, bcur[nt].w, acc[mt][nt]);
-          }
-#pragma unroll
-        for (int nt = 0; nt < MTN; ++nt) bcur[nt] = bnext[nt];
-      }
-      __syncthreads();
-    }
-  } else
   for (int kt = 0; kt < ktiles; ++kt) {
     if (kt + 1 < ktiles) {
-#if !(GEMM_ABL & 2)
       GEMM_STORE_TILE((kt + 1) & 1);
-#endif
-#if !(GEMM_ABL & 4)
       if (kt + 2 < ktiles) GEMM_LOAD_TILE(kt + 2);
-#endif
     }
     const float* ap = smem + (kt & 1) * TILE + a_off;
     const float* bp = smem + (kt & 1) * TILE + b_off;
@@ -517,7 +447,7 @@ __global__ __launch_bounds__(128 * NW, MT * MTN > 4 ? 2 : ((BK == 16 || BD) ? 4 
           acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
         }
     }
-    GEMM_KSYNC();
+    __syncthreads();
   }
   GEMM_STAMP(2);
 
@@ -636,23 +566,19 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
     const float* ab_ = (first_ ? A0 : A1) + (first_ ? k0_ : k0_ - g.K0) + s_c4;  \
     const size_t ld_ = first_ ? g.lda0 : g.lda1;                                 \
     if (WM == 2 || stage_a) areg = *reinterpret_cast<const float4*>(ab_ + ar * ld_); \
-    if (!(GEMM_ABL & 8)) {                                                       \
     wreg0 = *reinterpret_cast<const float4*>(w0p + k0_);                         \
     wreg1 = *reinterpret_cast<const float4*>(w1p + k0_);                         \
     wreg2 = *reinterpret_cast<const float4*>(w2p + k0_);                         \
     wreg3 = *reinterpret_cast<const float4*>(w3p + k0_);                         \
-    }                                                                            \
   } while (0)
 #define GW_STORE(buf_)                                                           \
   do {                                                                           \
     float* bs_ = smem + (buf_) * TILE + BM * LD + s_r0 * LD + s_c4;              \
     if (WM == 2 || stage_a) *reinterpret_cast<float4*>(smem + (buf_) * TILE + s_r0 * LD + s_c4) = areg; \
-    if (!(GEMM_ABL & 8)) {                                                       \
     *reinterpret_cast<float4*>(bs_) = wreg0;                                     \
     *reinterpret_cast<float4*>(bs_ + 128 * LD) = wreg1;                          \
     *reinterpret_cast<float4*>(bs_ + 256 * LD) = wreg2;                          \
     *reinterpret_cast<float4*>(bs_ + 384 * LD) = wreg3;                          \
-    }                                                                            \
   } while (0)
 
   f32x16 acc[2][4];
@@ -673,12 +599,8 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
   GEMM_STAMP(1);
   for (int kt = 0; kt < ktiles; ++kt) {
     if (kt + 1 < ktiles) {
-#if !(GEMM_ABL & 2)
       GW_STORE((kt + 1) & 1);
-#endif
-#if !(GEMM_ABL & 4)
       if (kt + 2 < ktiles) GW_LOAD(kt + 2);
-#endif
     }
     const float* ap = smem + (kt & 1) * TILE + a_off;
     const float* bp = smem + (kt & 1) * TILE + b_off;
@@ -699,7 +621,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
           acc[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc[mt][nt]);
         }
     }
-    GEMM_KSYNC();
+    __syncthreads();
   }
 #undef GW_LOAD
 #undef GW_STORE
@@ -854,12 +776,8 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
       for (int t = 0; t < 8; ++t) {
         const int T = c * 8 + t;
         if (T + 1 < 32) {
-#if !(GEMM_ABL & (2 | 8))
           FF_STORE((T + 1) & 1);
-#endif
-#if !(GEMM_ABL & (4 | 8))
           if (T + 2 < 32) FF_LOAD(T + 2);
-#endif
         }
         const float* ap = Hs + a_off3 + 16 * t;
         const float* bp = Ws + (T & 1) * W3T + b_off3;
@@ -880,7 +798,7 @@ __global__ __launch_bounds__(256 * WM, 2) void gemm_rows512_ln_gelu_kernel(GemmA
               acc2[mt][nt] = mfma32(af[mt].w, bf[nt].w, acc2[mt][nt]);
             }
         }
-        GEMM_KSYNC();
+        __syncthreads();
       }
     }
     GEMM_STAMP(4);
@@ -976,14 +894,14 @@ extern "C" int gfc_linear_layernorm_gelu(const float* A0, int lda0, int K0, cons
   return launch_rows512<2>(g, gamma, beta, (hipStream_t)stream);
 }
 
-template <int NW, int MT, int BK, int MTN = MT, bool BD = false>
+template <int NW, int MT, int BK, int MTN = MT>
 static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
   constexpr int BM = 64 * MT, BN = 32 * MTN * NW;
   // K-loop buffers, or the per-wave transpose patches of the rotary / residual epilogue if those are larger
-  constexpr size_t kloop = (size_t)2 * (BM + (BD ? 0 : BN)) * (BK + 4), patches = (size_t)2 * NW * 32 * (32 * MTN + 4);
+  constexpr size_t kloop = (size_t)2 * (BM + BN) * (BK + 4), patches = (size_t)2 * NW * 32 * (32 * MTN + 4);
   const size_t lds = (kloop > patches ? kloop : patches) * sizeof(float);
   static std::atomic<unsigned long long> lds_ok{0};  // per (instantiation, device): runtime.h
-  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_nt_kernel<NW, MT, BK, MTN, BD>, lds, lds_ok);
+  if (lds > 64 * 1024) gfc_allow_dynamic_lds((const void*)gemm_nt_kernel<NW, MT, BK, MTN>, lds, lds_ok);
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, batch);
   GemmArgs ga = g;
   ga.xcd_remap = gfc_knobs().xcd_remap != 0 && (long long)grid.x * grid.y * grid.z >= 16;
@@ -994,7 +912,7 @@ static int launch_gemm_t(const GemmArgs& g, int batch, hipStream_t st) {
 #if defined(GEMM_DIAG) && (GEMM_DIAG & 16)
   ga.stamps = g_diag_stamps;
 #endif
-  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK, MTN, BD>), grid, dim3(128 * NW), lds, st, ga);
+  hipLaunchKernelGGL((gemm_nt_kernel<NW, MT, BK, MTN>), grid, dim3(128 * NW), lds, st, ga);
   GFC_LAUNCH_CHECK();
   return GFC_OK;
 }
@@ -1003,7 +921,6 @@ static int launch_gemm(const GemmArgs& g, int batch, hipStream_t st) {
   // GFC_GEMM_TILE forces one of the two tiles for every problem size: 4 = 128x128 (K tile 16), 3 = 64x64 (K tile 32);
   // 0 / unset / anything else = by problem size.  (The 128x256, 256x128, 64x32, 16-deep 64x64 and LDS-DMA variants of
   // rounds 2-5 measured no faster anywhere and were removed in round 6: TUNING_LOG.md.)
-  if (g.wfrag) return gfc_knobs().gemm_tile == 16 ? launch_gemm_t<2, 2, 16, 2, true>(g, batch, st) : launch_gemm_t<2, 2, 32, 2, true>(g, batch, st);  // weights in fragment order: 128x128, A tile 32 (16) deep
   const int forced = gfc_knobs().gemm_tile;
   auto tiles = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * batch; };
   int choice = (forced == 3 || forced == 4) ? forced : 0;
@@ -1044,48 +961,6 @@ int gfc_linear_rot_packed(const float* A0, int lda0, int K0, const float* W, int
   g.A0 = A0; g.W = W; g.bias = bias; g.rot_cs = rot_cs; g.Y = Y;
   g.lda0 = lda0; g.ldw = ldw; g.ldy = ldy;
   g.K0 = K0; g.K1 = 0; g.M = M; g.N = N; g.rot_cols = rot_cols; g.alpha = 1.f;
-  return launch_gemm(g, 1, (hipStream_t)stream);
-}
-
-// W [N][K] (row stride ldw) -> MFMA-fragment order for the weight-direct GEMM (GemmArgs::wfrag):
-//   out[((nt * (K / 8) + kg) * 64 + lane) * 4 + s] = W[32 nt + (lane & 31)][8 kg + 4 (lane >> 5) + s]   (rows beyond N: 0)
-__global__ void pack_linear_frag_kernel(const float* __restrict__ W, int ldw, int N, int K, float* __restrict__ out) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total = (long long)((N + 31) / 32) * (K / 8) * 256;
-  if (i >= total) return;
-  const int s = (int)(i & 3), lane = (int)((i >> 2) & 63);
-  const long long blk = i >> 8;
-  const int kg = (int)(blk % (K / 8)), nt = (int)(blk / (K / 8));
-  const int n = 32 * nt + (lane & 31), k = 8 * kg + 4 * (lane >> 5) + s;
-  out[i] = n < N ? W[(size_t)n * ldw + k] : 0.f;
-}
-extern "C" size_t gfc_linear_frag_floats(int N, int K) { return (size_t)((N + 31) / 32) * 32 * (size_t)K; }
-extern "C" int gfc_pack_linear_frag(const float* W, int ldw, int N, int K, float* out, void* stream) {
-  if (!W || !out || N <= 0 || K <= 0 || K % 8 || ldw < K) return GFC_ERR_INVALID;
-  const long long total = (long long)((N + 31) / 32) * (K / 8) * 256;
-  hipLaunchKernelGGL(pack_linear_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, ldw,
-                     N, K, out);
-  GFC_LAUNCH_CHECK();
-  return GFC_OK;
-}
-// gfc_linear with the weights in fragment order (Wf from gfc_pack_linear_frag; K0 + K1 a multiple of 32)
-extern "C" int gfc_linear_wfrag(const float* A0, int lda0, int K0, const float* A1, int lda1, int K1, const float* Wf,
-                                const float* bias, const float* scale, const float* shift, float alpha,
-                                const float* residual, const float* rot_cos, const float* rot_sin, int rot_cols, float* Y,
-                                int ldy, int M, int N, void* stream) {
-  if (!A0 || !Wf || !Y || M <= 0 || N <= 0 || K0 <= 0 || K0 % 32 || K1 % 32 || K1 < 0) return GFC_ERR_INVALID;
-  if ((K1 > 0) != (A1 != nullptr)) return GFC_ERR_INVALID;
-  if ((scale == nullptr) != (shift == nullptr)) return GFC_ERR_INVALID;
-  if ((rot_cos == nullptr) != (rot_sin == nullptr)) return GFC_ERR_INVALID;
-  if (rot_cos && (rot_cols % 64 != 0)) return GFC_ERR_INVALID;
-  if (lda0 % 4 || (A1 && lda1 % 4) || (reinterpret_cast<size_t>(Wf) & 15)) return GFC_ERR_INVALID;
-  GemmArgs g = {};
-  g.A0 = A0; g.A1 = A1; g.W = Wf; g.bias = bias; g.scale = scale; g.shift = shift; g.residual = residual;
-  g.rot_cos = rot_cos; g.rot_sin = rot_sin; g.Y = Y;
-  g.strideA = g.strideW = g.strideY = 0;
-  g.lda0 = lda0; g.lda1 = lda1; g.ldw = K0 + K1; g.ldy = ldy;
-  g.K0 = K0; g.K1 = K1; g.M = M; g.N = N; g.rot_cols = rot_cols; g.alpha = alpha;
-  g.wfrag = 1;
   return launch_gemm(g, 1, (hipStream_t)stream);
 }
 
