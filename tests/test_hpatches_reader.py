@@ -256,6 +256,18 @@ def test_hpatches_pipeline_from_a_directory(tmp_path):
         a, b = np.array(pairwise[key], dtype=np.float64), np.array(results[key], dtype=np.float64)
         fin = np.isfinite(a)
         assert np.array_equal(fin, np.isfinite(b)) and np.allclose(a[fin], b[fin], rtol=1e-5, atol=1e-6), key
+    # the command line (a child process: rendezvous-free single GPU run) prints the same summaries
+    import json
+    import subprocess
+    import sys
+
+    root_dir = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "glue_factory_colon_amd.eval_hpatches", "--data_dir", str(root), "--open",
+                        "--pair_batch", "8", "--experiment_dir", str(tmp_path / "cli")], capture_output=True, text=True,
+                       cwd=root_dir, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cli = json.loads(r.stdout[r.stdout.index("{"):])
+    assert cli["mean_num_matches"] > 0 and set(cli) == set(summaries)
     # a second run reuses the prediction file (no model needed), as the reference does without --overwrite
     again, _ = pipe.run(tmp_path / "exp", None)
     assert again == summaries
