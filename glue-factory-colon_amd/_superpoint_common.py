@@ -134,6 +134,32 @@ def pad_keypoints_native(kpts, scores, counts, k, low, data, image):
     return kpts[:, :k].contiguous(), scores[:, :k].contiguous()
 
 
+def pad_keypoints_torch_cpu(kpts, scores, counts, k, low, data, image):
+    """`pad_and_stack(..., mode="random_c")` with THE REFERENCE'S random numbers (models/utils/misc.py:48-60,103-113):
+    the reference pads on the device its tensors live on -- the CPU in the parity configuration -- by drawing, per image
+    and per coordinate column, `k - d` values from torch's default CPU generator with `uniform_(min, max)` of the kept
+    key points (bounds (`low`, min(image_size)) for an image without any).  This opt-in path (`pad_random: "torch_cpu"`)
+    does exactly those draws in exactly that order, so that under the same `torch.manual_seed` the padded key points are
+    the reference's, bit for bit.  It costs what the default (`pad_keypoints_native`: one launch, the library's own
+    counter-based generator, no synchronisation) avoids: a host read of the counts and, for every image that needs
+    padding, a copy of its key points to the host and back."""
+    b, cap, _ = kpts.shape
+    n = counts.tolist()  # host synchronisation
+    high = float(data["image_size"].min().item()) if "image_size" in data else float(min(image.shape[-2:]))
+    for i in range(b):
+        d = min(int(n[i]), int(k))
+        scores[i, d:] = 0.0  # pad_and_stack(scores, ..., mode="zeros")
+        if d >= k:
+            continue
+        x = kpts[i, :d].cpu()
+        cols = [torch.empty(k - d, 1).uniform_(float(x[:, c].min()) if d > 0 else float(low),
+                                               float(x[:, c].max()) if d > 0 else high) for c in range(2)]
+        kpts[i, d:k] = torch.cat(cols, -1).to(kpts.device)
+    if cap == k:
+        return kpts, scores
+    return kpts[:, :k].contiguous(), scores[:, :k].contiguous()
+
+
 class SuperPointRunner:
     """Launch sequence for one extractor call."""
 
@@ -379,7 +405,7 @@ def specular_mask_bytes(data, b, device):
 
 def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection_threshold, max_num_keypoints,
                   force_num_keypoints, sample_mode, use_image_size_for_borders, dense_outputs, specular=None,
-                  refinement_radius=0, per_image=False, defer_counts=False):
+                  refinement_radius=0, per_image=False, defer_counts=False, pad_random="device"):
     """Shared `_forward` body (superpoint_open.py:126-232 / superpoint.py:206-379).
     specular: None, "before_topk" (superpoint_open.py:177-188) or "after_topk" (superpoint.py:310-328) when
     `data["specular_mask"]` is to be applied.
@@ -421,8 +447,12 @@ def run_extractor(runner, packed, data, *, nms_radius, remove_borders, detection
     if force_num_keypoints:
         if k is None:
             raise ValueError("force_num_keypoints needs max_num_keypoints")
-        # kept on the device: no host synchronisation on the batched path, one launch
-        kpts, ksc = pad_keypoints_native(kpts, ksc, counts, k, 0, data, image)
+        if pad_random == "torch_cpu":  # the reference's own random numbers (host round trip: parity runs)
+            kpts, ksc = pad_keypoints_torch_cpu(kpts, ksc, counts, k, 0, data, image)
+        elif pad_random == "device":  # kept on the device: no host synchronisation on the batched path, one launch
+            kpts, ksc = pad_keypoints_native(kpts, ksc, counts, k, 0, data, image)
+        else:
+            raise ValueError(f"pad_random {pad_random!r}: 'device' or 'torch_cpu'")
         counts_arg = None
     elif defer_counts and per_image and k is not None:
         desc, kout = runner.sample(desc_raw, kpts, counts, sample_mode)

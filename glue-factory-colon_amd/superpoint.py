@@ -38,6 +38,7 @@ class SuperPoint(BaseModel):
         "legacy_sampling": True,
         "filter_specular_keypoints": True,
         "weights": None,  # extension: local checkpoint path or "synthetic[:seed]" (the reference always downloads)
+        "pad_random": "device",  # extension: "torch_cpu" = the reference's padding draws (see superpoint_open.py)
     }
     required_data_keys = ["image"]
 
@@ -130,6 +131,7 @@ class SuperPoint(BaseModel):
                 nms_radius=conf_get(conf, "nms_radius"), remove_borders=conf_get(conf, "remove_borders"),
                 detection_threshold=conf_get(conf, "detection_threshold"), max_num_keypoints=k,
                 force_num_keypoints=conf_get(conf, "force_num_keypoints"),
+                pad_random=conf_get(conf, "pad_random", "device"),
                 sample_mode=SAMPLE_LEGACY if conf_get(conf, "legacy_sampling") else SAMPLE_FIXED,
                 use_image_size_for_borders=True, dense_outputs=conf_get(conf, "dense_outputs"), specular=specular,
                 refinement_radius=conf_get(conf, "refinement_radius", 0) or 0, per_image=per_image, defer_counts=defer_counts)

@@ -47,6 +47,10 @@ class SuperPoint(BaseModel):
         # on fp32 MFMA: same fp32 products / accumulation, 2.25x fewer of them); "fp32" = direct implicit GEMM on fp32
         # MFMA
         "conv_arithmetic": None,
+        # MI355X addition, source of the random padding of `force_num_keypoints` (models/utils/misc.py:48-60): "device" =
+        # one launch with the library's own generator, no host synchronisation; "torch_cpu" = the reference's draws from
+        # torch's CPU generator, bit for bit under the same torch.manual_seed (host round trip; parity runs)
+        "pad_random": "device",
     }
     required_data_keys = ["image"]
 
@@ -130,6 +134,7 @@ class SuperPoint(BaseModel):
                 detection_threshold=conf_get(self.conf, "detection_threshold"),
                 max_num_keypoints=conf_get(self.conf, "max_num_keypoints"),
                 force_num_keypoints=conf_get(self.conf, "force_num_keypoints"),
+                pad_random=conf_get(self.conf, "pad_random", "device"),
                 sample_mode=SAMPLE_OPEN, use_image_size_for_borders=False,
                 dense_outputs=conf_get(self.conf, "dense_outputs"), specular=specular, per_image=per_image, defer_counts=defer_counts)
 

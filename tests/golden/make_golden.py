@@ -633,7 +633,43 @@ def golden_c2_fp64_order():
     save("c2_fp64_order", keypoints=kpts, scores=scores)
 
 
+PAD_SEED = 4242
+
+
+def golden_pad_random_c():
+    """`force_num_keypoints` with images that keep FEWER than k key points: `pad_and_stack(mode="random_c")`
+    (models/utils/misc.py:48-60,103-113; superpoint_open.py:193-207) draws the padding from torch's CPU generator.  The
+    generator is seeded with PAD_SEED right before each call; the HIP module's opt-in `pad_random: "torch_cpu"` must
+    then reproduce the padded key points bit for bit (tests/test_gpu_models.py)."""
+    img = synthetic.synthetic_images(3, 120, 160, seed=51)
+    out = {"image": npy(img), "seed": np.array(PAD_SEED)}
+    m = make_spo(max_num_keypoints=680, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    counts = [int(make_spo(max_num_keypoints=4096, detection_threshold=0.0, nms_radius=3)({"image": img[i:i + 1]})
+                  ["keypoints"].shape[1]) for i in range(3)]
+    torch.manual_seed(PAD_SEED)
+    p = m({"image": img})
+    out["mixed_counts"] = np.array(counts)
+    assert min(counts) < 680 < max(counts), counts  # padded and un-padded images in one batch
+    for key in ("keypoints", "keypoint_scores"):
+        out["mixed_" + key] = npy(p[key])
+    out["mixed_descriptors_tail"] = npy(p["descriptors"][:, -48:])  # the padded rows (at most 13) and real rows before them
+    # with image_size (the bounds of an image WITHOUT key points) and a threshold nothing passes: all padding
+    size = torch.tensor([[150.0, 110.0]] * 3)
+    m0 = make_spo(max_num_keypoints=32, detection_threshold=2.0, nms_radius=3, force_num_keypoints=True)
+    torch.manual_seed(PAD_SEED)
+    p = m0({"image": img, "image_size": size})
+    out["empty_image_size"] = npy(size)
+    for key in ("keypoints", "keypoint_scores", "descriptors"):
+        out["empty_" + key] = npy(p[key])
+    print("pad_random_c: candidates per image", counts, "of 680; empty case keypoints in",
+          float(p["keypoints"].min()), float(p["keypoints"].max()))
+    save("pad_random_c", **out)
+
+
 if __name__ == "__main__":
+    if "--only-pad" in sys.argv:
+        golden_pad_random_c()
+        sys.exit(0)
     if "--only-c2-batch32" in sys.argv:
         golden_c2_batch32()
         sys.exit(0)
@@ -678,3 +714,4 @@ if __name__ == "__main__":
     golden_c2_batch32()
     golden_c4_pairs()
     golden_c2_fp64_order()
+    golden_pad_random_c()

@@ -153,6 +153,55 @@ def test_direct_conv_arithmetic_passes_the_model_parity_tests():
     assert 0 < d < 1e-5, d
 
 
+def test_force_num_keypoints_padding_with_the_references_random_numbers(golden):
+    """`force_num_keypoints` on images that keep fewer than k key points (superpoint_open.py:193-207 ->
+    models/utils/misc.py:48-60 `random_c`): with `pad_random: "torch_cpu"` and the generator seeded as the fixture's run
+    was, the PADDED key points are the reference's bit for bit (same draws, same order: per image, per coordinate
+    column), their scores are 0 and their descriptors (sampled at fractional positions) within 1e-4.  The default
+    (`pad_random: "device"`: one launch, own generator) is held to the properties only."""
+    g = golden("pad_random_c")
+    img = g["image"].to(DEV)
+    seed = int(g["seed"])
+    counts = g["mixed_counts"].tolist()
+    k = 680
+    m = spo(max_num_keypoints=k, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True, pad_random="torch_cpu")
+    torch.manual_seed(seed)
+    p = m({"image": img})
+    ref_kp, ref_sc, ref_de = g["mixed_keypoints"], g["mixed_keypoint_scores"], g["mixed_descriptors_tail"]
+    assert p["keypoints"].shape == (3, k, 2)
+    n_pad = 0
+    for i, d in enumerate(counts):
+        if d < k:  # all candidates in row-major order, then the padding: the arrays themselves are the reference's
+            assert torch.equal(p["keypoints"][i].cpu(), ref_kp[i]), i
+            assert maxerr(p["keypoint_scores"][i], ref_sc[i]) < 1e-5 and (p["keypoint_scores"][i, d:] == 0).all()
+            pad = p["keypoints"][i, d:].cpu()
+            assert len(pad) == k - d and (pad != pad.round()).any()  # really random, fractional positions
+            n_pad += k - d
+        else:  # more candidates than k: the sorted top-k list (order swaps between near ties allowed, parity_utils)
+            compare_keypoints(f"pad_mixed_img{i}", p["keypoints"][i], p["keypoint_scores"][i], p["descriptors"][i],
+                              ref_kp[i], ref_sc[i], None, radius=3)
+        if d < k:
+            assert maxerr(p["descriptors"][i, -48:], ref_de[i]) < 1e-4
+    assert n_pad == sum(k - d for d in counts if d < k) > 0 and any(d >= k for d in counts)
+    # no key point at all + image_size: every slot is padding inside (0, min(image_size)) (superpoint_open.py:200-203)
+    size = g["empty_image_size"].to(DEV)
+    m0 = spo(max_num_keypoints=32, detection_threshold=2.0, nms_radius=3, force_num_keypoints=True, pad_random="torch_cpu")
+    torch.manual_seed(seed)
+    p0 = m0({"image": img, "image_size": size})
+    assert torch.equal(p0["keypoints"].cpu(), g["empty_keypoints"]) and (p0["keypoint_scores"] == 0).all()
+    assert maxerr(p0["descriptors"], g["empty_descriptors"]) < 1e-4
+    # the default generator: same counts, same real key points, padding inside the same per-column bounds
+    md = spo(max_num_keypoints=k, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True)
+    pd_ = md({"image": img})
+    for i, d in enumerate(counts):
+        if d < k:
+            assert torch.equal(pd_["keypoints"][i, :d].cpu(), ref_kp[i, :d])
+            real, pad = ref_kp[i, :d], pd_["keypoints"][i, d:].cpu()
+            assert (pad >= real.min(0).values).all() and (pad <= real.max(0).values).all() and (pd_["keypoint_scores"][i, d:] == 0).all()
+    with pytest.raises(ValueError, match="pad_random"):
+        spo(max_num_keypoints=k, detection_threshold=0.0, nms_radius=3, force_num_keypoints=True, pad_random="numpy")({"image": img})
+
+
 def test_exact_erf_build_passes_the_parity_tests_and_bounds_the_gelu_approximation(golden, tmp_path):
     """The GELU of the FFN kernels uses a 14-instruction erf (Abramowitz & Stegun 7.1.26, csrc/common.h: gfc_gelu) instead
     of the exact-erf chain the reference's F.gelu evaluates (lightglue.py:143-148): a deliberate approximation on the hot
